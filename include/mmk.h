@@ -1,0 +1,157 @@
+/*
+ * mmk.h — C ABI of libmmk_hip.so: the MI355X (gfx950) implementation of the
+ * mm_masking learned-mask -> differentiable-ICP hot path.
+ *
+ * The reference (utiasASRL/mm_masking) is pure Python and has NO FFI of its own
+ * (SURVEY.md §2.1, §8b): each entry point below therefore cites the reference
+ * *Python* interface it replaces; the binding a maintainer adds is the ctypes
+ * stub shown in INTEGRATION.md (shipped as mm_masking_amd/_lib.py).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller unless marked host.
+ *    Kernels never allocate or free memory; scratch comes in through
+ *    (workspace, workspace_bytes) whose size the *_workspace_bytes() helpers give.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*) and returns
+ *    without synchronising (exception: mmk_icp_forward with check_every > 0).
+ *  - Return value: 0 on success, negative MMK_ERR_* otherwise; a message for the
+ *    calling thread is available from mmk_last_error().  No exceptions cross
+ *    the ABI, no global mutable state: safe for one-process-per-GPU use.
+ *  - Tensors are dense row-major fp32 unless stated; B = scan pairs in the batch.
+ */
+#ifndef MMK_H_
+#define MMK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMK_VERSION 100 /* 0.1.0 */
+
+#define MMK_OK 0
+#define MMK_ERR_ARG (-1)
+#define MMK_ERR_HIP (-2)
+#define MMK_ERR_WORKSPACE (-3)
+
+#define MMK_ICP_PT2PT 0
+#define MMK_ICP_PT2PL 1
+
+#define MMK_LOSS_NONE 0
+#define MMK_LOSS_CAUCHY 1
+#define MMK_LOSS_HUBER 2
+
+int mmk_version(void);
+const char *mmk_last_error(void);
+
+/* ------------------------------------------------------------------ dICP (external/dICP, absent upstream)
+ * Replaces dICP.ICP.ICP(...).icp(source, target, T_init=, weight=, trim_dist=,
+ * loss_fn=, dim=) as called at mm_masking/icp_weight_policy.py:281-287 (ctor
+ * :54-55; target_pad_val use mm_masking/icp_weight_dataset.py:59-61,395).
+ * Arithmetic: DESIGN.md §3 == oracle/dicp_ref.py.                                     */
+typedef struct {
+    int32_t B;          /* scan pairs                                            */
+    int32_t N;          /* padded source points per pair (zero rows carry weight 0) */
+    int32_t M;          /* padded target points per pair (target_pad_val rows)   */
+    int32_t tgt_cols;   /* 3 (xyz) or 6 (xyz|normal): icp_weight_dataset.py:397-398 */
+    int32_t dim;        /* 2 or 3 (reference passes dim=2)                        */
+    int32_t icp_type;   /* MMK_ICP_PT2PT | MMK_ICP_PT2PL (ctor icp_type)          */
+    int32_t loss;       /* MMK_LOSS_* from loss_fn["name"]                        */
+    float loss_k;       /* loss_fn["metric"]                                      */
+    float trim_dist;    /* trim_dist (5.0 at icp_weight_policy.py:279)            */
+    float tolerance;    /* ctor tolerance: a pair freezes once ||delta|| < tol    */
+    int32_t max_iter;   /* ctor max_iterations (K)                                */
+    int32_t save_state; /* 1: keep per-iteration correspondences for backward     */
+    int32_t check_every;/* >0: every that many iterations read the active flags
+                           back (synchronises `stream`) and stop when all pairs
+                           froze; 0: run max_iter iterations, never synchronise   */
+} mmk_icp_params;
+
+size_t mmk_icp_workspace_bytes(const mmk_icp_params *p);
+
+/* State arrays (device): idx_hist int32 (K,B,N) if save_state else (B,N);
+ * T_hist fp32 (K+1,B,16): poses before iteration k, T_hist[K] = result;
+ * delta_hist fp64 (K,B,6); A_hist fp64 (K,B,36) row-major p x p in the leading
+ * block; active_hist int32 (K+1,B): 1 while the pair still iterates.
+ * weight may be NULL (all ones).  iters_run (host int*, may be NULL).               */
+int mmk_icp_forward(const mmk_icp_params *p, const float *source /*B,N,3*/,
+                    const float *target /*B,M,tgt_cols*/, const float *weight /*B,N*/,
+                    const float *T_init /*B,16*/, float *T_out /*B,16*/,
+                    int32_t *idx_hist, float *T_hist, double *delta_hist, double *A_hist,
+                    int32_t *active_hist, void *workspace, size_t workspace_bytes,
+                    int *iters_run, void *stream);
+
+/* Reverse sweep over the saved state: grad_weight (B,N) = dL/dweight,
+ * grad_T_init (B,16, may be NULL) = dL/dT_init, given grad_T (B,16) = dL/dT_out.
+ * Replaces autograd through the unrolled dICP iterations
+ * (train_icp_weights.py:51 loss.backward()).                                           */
+int mmk_icp_backward(const mmk_icp_params *p, const float *source, const float *target,
+                     const float *weight, const int32_t *idx_hist, const float *T_hist,
+                     const double *delta_hist, const double *A_hist,
+                     const int32_t *active_hist, const float *grad_T /*B,16*/,
+                     float *grad_weight /*B,N*/, float *grad_T_init /*B,16 or NULL*/,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Stand-alone brute-force nearest neighbour (stage I2), the roofline kernel.
+ * target_planar: (B,dim,Mpad) produced by mmk_pack_target, Mpad = mmk_nn_padded_m(M).
+ * T (B,16) is applied to the source first (stage I1).  idx int32 (B,N), d2 fp32 (B,N). */
+int32_t mmk_nn_padded_m(int32_t M);
+int mmk_pack_target(const float *target /*B,M,tgt_cols*/, int32_t B, int32_t M,
+                    int32_t tgt_cols, int32_t dim, float *target_planar, void *stream);
+size_t mmk_nn_workspace_bytes(int32_t B, int32_t N, int32_t M, int32_t dim);
+int mmk_nn_search(const float *source /*B,N,3*/, const float *target_planar,
+                  const float *T /*B,16*/, int32_t B, int32_t N, int32_t M, int32_t dim,
+                  int32_t *idx, float *d2, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/* ------------------------------------------------------------------ radar_utils.py
+ * mmk_cfar_mask        <- cfar_mask                      radar_utils.py:29-69
+ * mmk_extract_peaks    <- extract_pc (+mean_peaks_parallel_fast, pol_2_cart)
+ *                                                        radar_utils.py:71-106,167-195
+ * mmk_polar_to_cart    <- radar_polar_to_cartesian_diff  radar_utils.py:258-336
+ * mmk_sample_weights_* <- extract_weights (fwd + autograd bwd) radar_utils.py:108-128
+ * mmk_bev_raster       <- extract_bev_from_pts           radar_utils.py:142-165      */
+
+/* GO-CFAR on (B,A,R) polar power.  w2/guard/mincol/maxcol as derived at
+ * radar_utils.py:34-39 by the caller.  diff: 0 hard (x>thres), 1 soft (tanh+hardshrink). */
+int mmk_cfar_mask(const float *raw, int32_t B, int32_t A, int32_t R, int32_t w2,
+                  int32_t guard, int32_t mincol, int32_t maxcol, float a_thresh,
+                  float b_thresh, int32_t diff, float steep_fact, float *mask,
+                  void *stream);
+
+size_t mmk_extract_peaks_workspace_bytes(int32_t B, int32_t A, int32_t R, int32_t max_pts);
+/* Blob-centre extraction.  out_pc (B,max_pts,3) zero padded in the reference's
+ * azimuth-major order; out_count int32 (B) = points the reference would return
+ * (may exceed max_pts: then the cloud is truncated); T_ab (B,16) may be NULL.          */
+int mmk_extract_peaks(const float *mask, int32_t B, int32_t A, int32_t R, float res,
+                      const float *azimuths /*B,A*/, const float *times /*B,A*/,
+                      const float *T_ab, int32_t diff, float steep_fact, int32_t max_pts,
+                      float *out_pc, int32_t *out_count, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* Polar (B,A,R) -> Cartesian (B,W,W) bilinear resample.  range_grid/angle_grid (W,W)
+ * are form_cart_range_angle_grid's outputs (radar_utils.py:399-419), built by the host. */
+int mmk_polar_to_cart(const float *polar, const float *azimuths /*B,A*/,
+                      const float *range_grid, const float *angle_grid, int32_t B,
+                      int32_t A, int32_t R, int32_t W, float radar_resolution,
+                      int32_t interpolate_crossover, int32_t fix_wobble, float *cart,
+                      void *stream);
+
+/* weights[b,n] = bilinear(mask[b], point n) with zero padding; fake points
+ * (x==0 && y==0) get 0.  cart_resolution/W as point_to_cart_idx (radar_utils.py:374-397). */
+int mmk_sample_weights_fwd(const float *mask /*B,H,W*/, const float *pc /*B,N,pc_cols*/,
+                           int32_t B, int32_t N, int32_t pc_cols, int32_t H, int32_t W,
+                           float cart_resolution, float *weights /*B,N*/, void *stream);
+/* grad_mask (B,H,W) is zero-filled here, then receives the scatter-add. */
+int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, int32_t B,
+                           int32_t N, int32_t pc_cols, int32_t H, int32_t W,
+                           float cart_resolution, float *grad_mask, void *stream);
+
+int mmk_bev_raster(const float *pc /*B,M,pc_cols*/, int32_t B, int32_t M, int32_t pc_cols,
+                   int32_t W, float cart_resolution, float *bev /*B,W,W*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMK_H_ */

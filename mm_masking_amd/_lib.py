@@ -1,0 +1,137 @@
+"""ctypes binding of libmmk_hip.so (the C ABI declared in include/mmk.h).
+
+This is the stub a maintainer of the reference would add: the
+reference has no FFI of its own, so every entry point replaces a *Python* call
+site of mm_masking (cited in include/mmk.h).  PyTorch is only the owner of the
+device buffers and of the HIP stream the kernels are enqueued on.
+
+The library is mandatory: there is NO CPU or PyTorch fallback.  ``lib()`` raises
+if the shared object is missing or fails to load, and every wrapper raises if a
+tensor is not a contiguous tensor of the expected dtype on a HIP device.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+SO_PATH = os.path.join(_HERE, "libmmk_hip.so")
+SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip"]
+
+_lib = None
+
+c_f32p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+
+
+class MmkError(RuntimeError):
+    pass
+
+
+class IcpParams(ctypes.Structure):
+    """mmk_icp_params of include/mmk.h."""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("M", ctypes.c_int32),
+                ("tgt_cols", ctypes.c_int32), ("dim", ctypes.c_int32), ("icp_type", ctypes.c_int32),
+                ("loss", ctypes.c_int32), ("loss_k", ctypes.c_float), ("trim_dist", ctypes.c_float),
+                ("tolerance", ctypes.c_float), ("max_iter", ctypes.c_int32), ("save_state", ctypes.c_int32),
+                ("check_every", ctypes.c_int32)]
+
+
+ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
+LOSSES = {None: 0, "none": 0, "l2": 0, "cauchy": 1, "huber": 2}
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into mm_masking_amd/libmmk_hip.so
+    (hipcc cross-compiles without a GPU).  -ffp-contract=off is part of the
+    numerical contract."""
+    srcs = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    deps = srcs + [os.path.join(_HERE, "csrc", "mmk_common.h"), os.path.join(_ROOT, "include", "mmk.h")]
+    if os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I", os.path.join(_ROOT, "include"), "-o", SO_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def _declare(lib):
+    i32, f32, sz = ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
+    P = ctypes.POINTER(IcpParams)
+    sig = {
+        "mmk_version": (ctypes.c_int, []),
+        "mmk_last_error": (ctypes.c_char_p, []),
+        "mmk_icp_workspace_bytes": (sz, [P]),
+        "mmk_icp_forward": (ctypes.c_int, [P] + [c_vp] * 10 + [c_vp, sz, ctypes.POINTER(ctypes.c_int), c_vp]),
+        "mmk_icp_backward": (ctypes.c_int, [P] + [c_vp] * 11 + [c_vp, sz, c_vp]),
+        "mmk_nn_padded_m": (i32, [i32]),
+        "mmk_pack_target": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
+        "mmk_nn_workspace_bytes": (sz, [i32, i32, i32, i32]),
+        "mmk_nn_search": (ctypes.c_int, [c_vp, c_vp, c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp, sz, c_vp]),
+        "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
+        "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
+        "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,
+                                             c_vp, sz, c_vp]),
+        "mmk_polar_to_cart": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, f32, i32, i32, c_vp, c_vp]),
+        "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
+        "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
+        "mmk_bev_raster": (ctypes.c_int, [c_vp, i32, i32, i32, i32, f32, c_vp, c_vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTED = None
+
+
+def lib():
+    """The loaded C-ABI library; raises MmkError when it is absent (no fallback)."""
+    global _lib, EXPORTED
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MmkError("libmmk_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  The HIP path has no CPU fallback.")
+        try:
+            loaded = ctypes.CDLL(SO_PATH)
+        except OSError as e:
+            raise MmkError("cannot load %s: %s" % (SO_PATH, e)) from e
+        EXPORTED = _declare(loaded)
+        _lib = loaded
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MmkError("libmmk_hip: %s (code %d)" % (lib().mmk_last_error().decode(errors="replace"), rc))
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise MmkError("%s must live on a HIP device (got %s); the kernels have no CPU path" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise MmkError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise MmkError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def dev_f32(t, device):
+    """Reference call sites hand over CPU or device tensors of any float type
+    (icp_weight_policy.py:130-134 moves them itself); normalise to contiguous
+    fp32 on `device`."""
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()

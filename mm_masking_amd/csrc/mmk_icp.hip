@@ -1,0 +1,1066 @@
+// Differentiable ICP on gfx950: brute-force nearest neighbour (LDS-tiled), robust
+// weighted normal-equation accumulation (wave64 shuffle reduction), 3x3 / 6x6
+// Gauss-Newton solve + SE(2)/SE(3) exponential update, and the reverse sweep.
+//
+// Replaces dICP.ICP.ICP(...).icp(...) as called from the reference at
+// mm_masking/icp_weight_policy.py:281-287 (external/dICP itself is absent from the
+// reference tree).  The arithmetic is the normative spec of DESIGN.md §3 and is
+// restated on the CPU in oracle/dicp_ref.py + oracle/nn_search.c; per-point fp32
+// operations are written in the same order as there and this file MUST be built
+// with -ffp-contract=off so that only the explicit fmaf calls fuse.
+#include <math.h>
+
+#include <algorithm>
+
+#include "mmk_common.h"
+
+namespace {
+
+constexpr int NN_THREADS = 256;
+constexpr int NN_TILE = 1024;  // target points staged in LDS per tile
+constexpr int NN_CHUNK = 8;    // targets per running-minimum chunk
+constexpr int NN_P = 2;        // source points held in registers per lane
+constexpr float NN_PAD = 3.0e18f;
+constexpr int ACC_THREADS = 256;
+
+__host__ __device__ constexpr int nacc(int dim) { return dim == 2 ? 9 : 27; }
+__host__ __device__ constexpr int npose(int dim) { return dim == 2 ? 6 : 12; }
+
+// ------------------------------------------------------------------------------------------
+// I1: p = R s + t, fp32, individually rounded left to right (oracle: transform_points).
+template <int DIM>
+__device__ __forceinline__ void transform_point(const float *T, const float s[3], float p[DIM])
+{
+    if constexpr (DIM == 2) {
+        p[0] = (T[0] * s[0] + T[1] * s[1]) + T[3];
+        p[1] = (T[4] * s[0] + T[5] * s[1]) + T[7];
+    } else {
+        p[0] = ((T[0] * s[0] + T[1] * s[1]) + T[2] * s[2]) + T[3];
+        p[1] = ((T[4] * s[0] + T[5] * s[1]) + T[6] * s[2]) + T[7];
+        p[2] = ((T[8] * s[0] + T[9] * s[1]) + T[10] * s[2]) + T[11];
+    }
+}
+
+// Squared distance in the fmaf form of oracle/nn_search.c.
+template <int DIM>
+__device__ __forceinline__ float nn_dist(float tx, float ty, float tz, const float p[DIM])
+{
+    float dx = tx - p[0];
+    float dy = ty - p[1];
+    float d = __builtin_fmaf(dy, dy, dx * dx);
+    if constexpr (DIM == 3) {
+        float dz = tz - p[2];
+        d = __builtin_fmaf(dz, dz, d);
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------
+// Planar, padded copy of the target coordinates: (B,M,cols) AoS -> (B,DIM,Mpad).
+__global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int cols, int dim, int Mpad,
+                                   float *__restrict__ out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = blockIdx.y;
+    if (j >= Mpad) return;
+    for (int c = 0; c < dim; ++c) {
+        float v = NN_PAD;
+        if (j < M) v = tgt[((size_t)b * M + j) * cols + c];
+        out[((size_t)b * dim + c) * Mpad + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// I2: brute-force NN.  One lane owns NN_P transformed source points in VGPRs; the target
+// streams through LDS in planar tiles (wave-uniform ds_read_b128 broadcasts).  Per chunk
+// of 8 targets only the chunk minimum is tracked (v_min3) together with the id of the
+// first chunk that attained it; the winning chunk is re-scanned at the end with a strict
+// '<' in ascending order, which yields exactly the lowest-index argmin of the oracle.
+// Grid: 1-D, XCD-aware: blocks of one pair share an XCD (b % 8 label) so its target
+// planes stay in that XCD's L2.
+template <int DIM>
+__global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ Tk,
+    const int32_t *__restrict__ active, int B, int N, int Mpad, int nsb, int S, int tiles_per_split,
+    float *__restrict__ pd, int32_t *__restrict__ pi)
+{
+    __shared__ __attribute__((aligned(16))) float lt[DIM][NN_TILE];
+
+    const int g = blockIdx.x;
+    const int xcd = g & 7;
+    const int slot = g >> 3;
+    const int nb = nsb * S;
+    const int b = (slot / nb) * 8 + xcd;
+    if (b >= B) return;
+    if (active != nullptr && active[b] == 0) return;
+    const int within = slot % nb;
+    const int sb = within / S;
+    const int split = within % S;
+    const int tid = threadIdx.x;
+
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
+
+    float p[NN_P][DIM];
+    float best[NN_P];
+    int bch[NN_P];
+    int pidx[NN_P];
+#pragma unroll
+    for (int q = 0; q < NN_P; ++q) {
+        int i = sb * (NN_THREADS * NN_P) + q * NN_THREADS + tid;
+        pidx[q] = i;
+        float s[3] = {0.f, 0.f, 0.f};
+        if (i < N) {
+            const float *sp = src + ((size_t)b * N + i) * 3;
+            s[0] = sp[0];
+            s[1] = sp[1];
+            s[2] = sp[2];
+        }
+        transform_point<DIM>(T, s, p[q]);
+        best[q] = INFINITY;
+        bch[q] = 0;
+    }
+
+    const int ntiles = Mpad / NN_TILE;
+    const int t0 = split * tiles_per_split;
+    const int t1 = min(ntiles, t0 + tiles_per_split);
+    const float *tb = tgtp + (size_t)b * DIM * Mpad;
+
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            // NN_TILE floats per plane = 256 lanes x float4
+            const float4 v = *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
+            *reinterpret_cast<float4 *>(&lt[c][tid * 4]) = v;
+        }
+        __syncthreads();
+        const int chunk0 = t * (NN_TILE / NN_CHUNK);
+#pragma unroll 2
+        for (int c = 0; c < NN_TILE / NN_CHUNK; ++c) {
+            float tx[NN_CHUNK], ty[NN_CHUNK], tz[NN_CHUNK];
+#pragma unroll
+            for (int h = 0; h < NN_CHUNK / 4; ++h) {
+                float4 vx = *reinterpret_cast<const float4 *>(&lt[0][c * NN_CHUNK + h * 4]);
+                float4 vy = *reinterpret_cast<const float4 *>(&lt[1][c * NN_CHUNK + h * 4]);
+                tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
+                ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
+                if (DIM == 3) {
+                    float4 vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][c * NN_CHUNK + h * 4]);
+                    tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
+                } else {
+                    tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NN_P; ++q) {
+                float d[NN_CHUNK];
+#pragma unroll
+                for (int j = 0; j < NN_CHUNK; ++j) d[j] = nn_dist<DIM>(tx[j], ty[j], tz[j], p[q]);
+                float m = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
+                m = __builtin_fminf(__builtin_fminf(m, d[3]), d[4]);
+                m = __builtin_fminf(__builtin_fminf(m, d[5]), d[6]);
+                m = __builtin_fminf(m, d[7]);
+                const bool better = m < best[q];
+                best[q] = better ? m : best[q];
+                bch[q] = better ? (chunk0 + c) : bch[q];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < NN_P; ++q) {
+        const int i = pidx[q];
+        if (i >= N) continue;
+        const int j0 = bch[q] * NN_CHUNK;
+        float cur = INFINITY;
+        int jj = j0;
+#pragma unroll
+        for (int j = 0; j < NN_CHUNK; ++j) {
+            float tx = tb[j0 + j];
+            float ty = tb[(size_t)Mpad + j0 + j];
+            float tz = (DIM == 3) ? tb[(size_t)2 * Mpad + j0 + j] : 0.f;
+            float d = nn_dist<DIM>(tx, ty, tz, p[q]);
+            if (d < cur) {
+                cur = d;
+                jj = j0 + j;
+            }
+        }
+        const size_t o = ((size_t)b * S + split) * N + i;
+        pd[o] = cur;
+        pi[o] = jj;
+    }
+}
+
+// Merge the per-split partial results (ascending split order, strict '<').
+__device__ __forceinline__ void nn_merge(const float *__restrict__ pd, const int32_t *__restrict__ pi, int b,
+                                         int i, int N, int S, float &best, int &bi)
+{
+    best = INFINITY;
+    bi = 0;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = ((size_t)b * S + s) * N + i;
+        const float d = pd[o];
+        if (d < best) {
+            best = d;
+            bi = pi[o];
+        }
+    }
+}
+
+__global__ void nn_merge_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi, int N, int S,
+                                int32_t *__restrict__ idx, float *__restrict__ d2)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= N) return;
+    float best;
+    int bi;
+    nn_merge(pd, pi, b, i, N, S, best, bi);
+    idx[(size_t)b * N + i] = bi;
+    d2[(size_t)b * N + i] = best;
+}
+
+// ------------------------------------------------------------------------------------------
+// I3 + I4 per-point terms (oracle: per_point_terms).
+template <int DIM, int TYPE>
+struct PointTerms {
+    static constexpr int P = (DIM == 2) ? 3 : 6;
+    static constexpr int NR = (TYPE == MMK_ICP_PT2PT) ? DIM : 1;
+    float s[3];
+    float p[DIM];
+    float ev[DIM];
+    float n[DIM];
+    float J[NR][P];
+    float er[NR];
+    float d2, r2, keep, rho, w, omega;
+};
+
+template <int DIM, int TYPE>
+__device__ __forceinline__ void point_terms(PointTerms<DIM, TYPE> &t, const float *T, const float *srow,
+                                            const float *trow, float omega, int loss, float k, float k2,
+                                            float trim2)
+{
+    constexpr int P = PointTerms<DIM, TYPE>::P;
+    constexpr int NR = PointTerms<DIM, TYPE>::NR;
+    t.s[0] = srow[0];
+    t.s[1] = srow[1];
+    t.s[2] = srow[2];
+    transform_point<DIM>(T, t.s, t.p);
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) t.ev[c] = trow[c] - t.p[c];
+    float d2 = t.ev[0] * t.ev[0] + t.ev[1] * t.ev[1];
+    if constexpr (DIM == 3) d2 = d2 + t.ev[2] * t.ev[2];
+    t.d2 = d2;
+    t.keep = (d2 < trim2) ? 1.f : 0.f;
+    if (TYPE == MMK_ICP_PT2PL) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) t.n[c] = trow[3 + c];
+        float e = t.n[0] * t.ev[0] + t.n[1] * t.ev[1];
+        if constexpr (DIM == 3) e = e + t.n[2] * t.ev[2];
+        t.er[0] = e;
+        t.r2 = e * e;
+        if (DIM == 2) {
+            t.J[0][0] = t.n[0];
+            t.J[0][1] = t.n[1];
+            t.J[0][2] = t.n[1] * t.p[0] - t.n[0] * t.p[1];
+        } else {
+            t.J[0][0] = t.n[0];
+            t.J[0][1] = t.n[1];
+            t.J[0][2] = t.n[DIM - 1];
+            t.J[0][P - 3] = t.p[1] * t.n[DIM - 1] - t.p[DIM - 1] * t.n[1];
+            t.J[0][P - 2] = t.p[DIM - 1] * t.n[0] - t.p[0] * t.n[DIM - 1];
+            t.J[0][P - 1] = t.p[0] * t.n[1] - t.p[1] * t.n[0];
+        }
+    } else {
+        t.r2 = d2;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            t.er[r] = t.ev[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) t.J[r][c] = 0.f;
+            t.J[r][r] = 1.f;
+        }
+        if (DIM == 2) {
+            t.J[0][2] = -t.p[1];
+            t.J[NR - 1][2] = t.p[0];
+        } else {
+            const float px = t.p[0], py = t.p[1], pz = t.p[DIM - 1];
+            t.J[0][P - 2] = pz;
+            t.J[0][P - 1] = -py;
+            t.J[1 % NR][P - 3] = -pz;
+            t.J[1 % NR][P - 1] = px;
+            t.J[2 % NR][P - 3] = py;
+            t.J[2 % NR][P - 2] = -px;
+        }
+    }
+    float rho = 1.f;
+    if (loss == MMK_LOSS_CAUCHY) {
+        rho = 1.0f / (1.0f + t.r2 / k2);
+    } else if (loss == MMK_LOSS_HUBER) {
+        const float r = sqrtf(t.r2);
+        rho = (r <= k) ? 1.f : k / r;
+    }
+    t.rho = rho;
+    t.omega = omega;
+    t.w = (omega * t.keep) * rho;
+}
+
+// Accumulate A (upper triangle, row-major) and b for one pair; one point per thread.
+template <int DIM, int TYPE>
+__global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgt, int tgt_cols,
+    const float *__restrict__ weight, const float *__restrict__ Tk, const int32_t *__restrict__ active,
+    const float *__restrict__ pd, const int32_t *__restrict__ pi, int S, int32_t *__restrict__ idx_out, int N,
+    int M, int loss, float k, float k2, float trim2, double *__restrict__ partials)
+{
+    constexpr int P = PointTerms<DIM, TYPE>::P;
+    constexpr int NR = PointTerms<DIM, TYPE>::NR;
+    constexpr int NACC = nacc(DIM);
+    const int b = blockIdx.y;
+    if (active[b] == 0) return;
+    const int i = blockIdx.x * ACC_THREADS + threadIdx.x;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+
+    if (i < N) {
+        float T[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T[q] = Tk[(size_t)b * 16 + q];
+        float bestd;
+        int j;
+        nn_merge(pd, pi, b, i, N, S, bestd, j);
+        idx_out[(size_t)b * N + i] = j;
+        const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
+        PointTerms<DIM, TYPE> t;
+        point_terms<DIM, TYPE>(t, T, src + ((size_t)b * N + i) * 3, tgt + ((size_t)b * M + j) * tgt_cols, omega,
+                               loss, k, k2, trim2);
+        int a = 0;
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+#pragma unroll
+            for (int n = m; n < P; ++n) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) v += (double)(t.w * t.J[r][m]) * (double)t.J[r][n];
+                acc[a++] = v;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v += (double)(t.w * t.J[r][m]) * (double)t.er[r];
+            acc[a++] = v;
+        }
+    }
+
+    __shared__ double red[ACC_THREADS / 64][NACC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) red[wv][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
+        partials[((size_t)b * gridDim.x + blockIdx.x) * NACC + threadIdx.x] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small dense fp64 helpers (one lane).
+template <int P>
+__device__ bool chol_solve(const double *A /*P*P row-major symmetric*/, const double *rhs, double *x)
+{
+    double L[P][P];
+    bool ok = true;
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) {
+            L[i][j] = 0.0;
+            if (!isfinite(A[i * P + j])) ok = false;
+        }
+    for (int j = 0; j < P && ok; ++j) {
+        double d = A[j * P + j];
+        for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
+        if (!(d > 0.0)) {
+            ok = false;
+            break;
+        }
+        d = sqrt(d);
+        L[j][j] = d;
+        for (int i = j + 1; i < P; ++i) {
+            double v = A[i * P + j];
+            for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
+            L[i][j] = v / d;
+        }
+    }
+    if (!ok) {
+        for (int i = 0; i < P; ++i) x[i] = 0.0;
+        return false;
+    }
+    double y[P];
+    for (int i = 0; i < P; ++i) {
+        double v = rhs[i];
+        for (int q = 0; q < i; ++q) v -= L[i][q] * y[q];
+        y[i] = v / L[i][i];
+    }
+    for (int i = P - 1; i >= 0; --i) {
+        double v = y[i];
+        for (int q = i + 1; q < P; ++q) v -= L[q][i] * x[q];
+        x[i] = v / L[i][i];
+    }
+    return true;
+}
+
+// Closed-form Exp(delta) -> 4x4 (oracle: se_exp).
+template <int DIM>
+__device__ void se_exp(const double *dl, double E[16])
+{
+    for (int i = 0; i < 16; ++i) E[i] = 0.0;
+    E[0] = E[5] = E[10] = E[15] = 1.0;
+    if (DIM == 2) {
+        const double x = dl[0], y = dl[1], th = dl[2];
+        const double th2 = th * th;
+        double a, bb;
+        if (th2 < 1e-8) {
+            a = 1.0 - th2 / 6.0 + th2 * th2 / 120.0;
+            bb = th * (0.5 - th2 / 24.0 + th2 * th2 / 720.0);
+        } else {
+            a = sin(th) / th;
+            bb = (1.0 - cos(th)) / th;
+        }
+        const double c = cos(th), s = sin(th);
+        E[0] = c; E[1] = -s; E[3] = a * x - bb * y;
+        E[4] = s; E[5] = c;  E[7] = bb * x + a * y;
+    } else {
+        const double *rho = dl, *phi = dl + 3;
+        const double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+        double A_, B_, C_;
+        if (th2 < 1e-8) {
+            A_ = 1.0 - th2 / 6.0 + th2 * th2 / 120.0;
+            B_ = 0.5 - th2 / 24.0 + th2 * th2 / 720.0;
+            C_ = 1.0 / 6.0 - th2 / 120.0 + th2 * th2 / 5040.0;
+        } else {
+            const double th = sqrt(th2);
+            A_ = sin(th) / th;
+            B_ = (1.0 - cos(th)) / th2;
+            C_ = (th - sin(th)) / (th2 * th);
+        }
+        const double K[9] = {0.0, -phi[2], phi[1], phi[2], 0.0, -phi[0], -phi[1], phi[0], 0.0};
+        double K2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                for (int q = 0; q < 3; ++q) v += K[i * 3 + q] * K[q * 3 + j];
+                K2[i * 3 + j] = v;
+            }
+        for (int i = 0; i < 3; ++i) {
+            double tv = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                const double id = (i == j) ? 1.0 : 0.0;
+                E[i * 4 + j] = id + A_ * K[i * 3 + j] + B_ * K2[i * 3 + j];
+                tv += (id + B_ * K[i * 3 + j] + C_ * K2[i * 3 + j]) * rho[j];
+            }
+            E[i * 4 + 3] = tv;
+        }
+    }
+}
+
+// I5 + I6: sum the block partials in a fixed order, solve, update the pose.
+template <int DIM>
+__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ partials, int nblk,
+                                                       const float *__restrict__ T_in, float *__restrict__ T_out,
+                                                       double *__restrict__ delta_out, double *__restrict__ A_out,
+                                                       const int32_t *__restrict__ active_in,
+                                                       int32_t *__restrict__ active_out, float tol)
+{
+    constexpr int P = (DIM == 2) ? 3 : 6;
+    constexpr int NACC = nacc(DIM);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ double acc[NACC];
+    const bool act = active_in[b] != 0;
+    if (lane < NACC) {
+        double v = 0.0;
+        if (act)
+            for (int q = 0; q < nblk; ++q) v += partials[((size_t)b * nblk + q) * NACC + lane];
+        acc[lane] = v;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double A[P * P], rhs[P], dl[6] = {0, 0, 0, 0, 0, 0};
+    int a = 0;
+    for (int m = 0; m < P; ++m)
+        for (int n = m; n < P; ++n) {
+            A[m * P + n] = acc[a];
+            A[n * P + m] = acc[a];
+            ++a;
+        }
+    for (int m = 0; m < P; ++m) rhs[m] = acc[a++];
+    for (int q = 0; q < 36; ++q) A_out[(size_t)b * 36 + q] = (q < P * P) ? A[q] : 0.0;
+    if (act) chol_solve<P>(A, rhs, dl);
+    for (int q = 0; q < 6; ++q) delta_out[(size_t)b * 6 + q] = dl[q];
+    if (!act) {
+        for (int q = 0; q < 16; ++q) T_out[(size_t)b * 16 + q] = T_in[(size_t)b * 16 + q];
+        active_out[b] = 0;
+        return;
+    }
+    double E[16];
+    se_exp<DIM>(dl, E);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double v = 0.0;
+            for (int q = 0; q < 4; ++q) v += E[i * 4 + q] * (double)T_in[(size_t)b * 16 + q * 4 + j];
+            T_out[(size_t)b * 16 + i * 4 + j] = (float)v;
+        }
+    double nrm = 0.0;
+    for (int q = 0; q < P; ++q) nrm += dl[q] * dl[q];
+    active_out[b] = (sqrt(nrm) < (double)tol) ? 0 : 1;
+}
+
+__global__ void fill_i32_kernel(int32_t *p, int n, int32_t v)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// I7 backward, per-pair part.  One wave per pair; the 64 lanes are the 8x8 entries of the
+// block matrix [[X^T, Ebar],[0, X^T]] whose exponential carries exp(X)^T (top-left) and the
+// adjoint of the exponential map applied to Ebar (top-right).
+template <int DIM>
+__global__ __launch_bounds__(64) void icp_bwd_pair_kernel(
+    const double *__restrict__ Gdir_in, const double *__restrict__ pparts, int nparts,
+    const float *__restrict__ Tk, const double *__restrict__ delta, const double *__restrict__ Amat,
+    const int32_t *__restrict__ active, double *__restrict__ Gdir_out, double *__restrict__ lam_out)
+{
+    constexpr int P = (DIM == 2) ? 3 : 6;
+    constexpr int NP = npose(DIM);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ double G[16], Eb[16], X[16], M0[64], R0[64], R1[64];
+
+    // full gradient w.r.t. T_{k+1}: direct part + point path of the later iteration
+    if (lane < 16) {
+        double v = Gdir_in[(size_t)b * 16 + lane];
+        const int r = lane >> 2, c = lane & 3;
+        int slot = -1;
+        if (r < DIM && c < DIM) slot = r * DIM + c;
+        if (r < DIM && c == 3) slot = DIM * DIM + r;
+        if (slot >= 0)
+            for (int q = 0; q < nparts; ++q) v += pparts[((size_t)b * nparts + q) * NP + slot];
+        G[lane] = v;
+    }
+    __syncthreads();
+    const bool act = (active != nullptr) && active[b] != 0;
+    if (!act) {
+        if (lane < 16) Gdir_out[(size_t)b * 16 + lane] = G[lane];
+        if (lane < 6 && lam_out) lam_out[(size_t)b * 6 + lane] = 0.0;
+        return;
+    }
+    const double *dl = delta + (size_t)b * 6;
+    if (lane < 16) {
+        const int r = lane >> 2, c = lane & 3;
+        // Ebar = G * T_k^T
+        double v = 0.0;
+        for (int q = 0; q < 4; ++q) v += G[r * 4 + q] * (double)Tk[(size_t)b * 16 + c * 4 + q];
+        Eb[lane] = v;
+        double x = 0.0;
+        if (DIM == 2) {
+            if (r == 0 && c == 3) x = dl[0];
+            if (r == 1 && c == 3) x = dl[1];
+            if (r == 1 && c == 0) x = dl[2];
+            if (r == 0 && c == 1) x = -dl[2];
+        } else {
+            if (c == 3 && r < 3) x = dl[r];
+            if (r == 2 && c == 1) x = dl[3];
+            if (r == 1 && c == 2) x = -dl[3];
+            if (r == 0 && c == 2) x = dl[4];
+            if (r == 2 && c == 0) x = -dl[4];
+            if (r == 1 && c == 0) x = dl[5];
+            if (r == 0 && c == 1) x = -dl[5];
+        }
+        X[lane] = x;
+    }
+    __syncthreads();
+    const int i8 = lane >> 3, j8 = lane & 7;
+    {
+        double m = 0.0;
+        const double sc = 1.0 / 64.0;
+        if (i8 < 4 && j8 < 4) m = X[j8 * 4 + i8] * sc;             // X^T
+        else if (i8 >= 4 && j8 >= 4) m = X[(j8 - 4) * 4 + (i8 - 4)] * sc;
+        else if (i8 < 4 && j8 >= 4) m = Eb[i8 * 4 + (j8 - 4)] * sc;
+        M0[lane] = m;
+        R0[lane] = ((i8 == j8) ? 1.0 : 0.0) + m / 13.0;
+    }
+    __syncthreads();
+    double *cur = R0, *nxt = R1;
+    // Horner: R = I + M R / n, n = 12 .. 1
+    for (int n = 12; n >= 1; --n) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += M0[i8 * 8 + q] * cur[q * 8 + j8];
+        nxt[lane] = ((i8 == j8) ? 1.0 : 0.0) + v / (double)n;
+        __syncthreads();
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    for (int sq = 0; sq < 6; ++sq) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += cur[i8 * 8 + q] * cur[q * 8 + j8];
+        nxt[lane] = v;
+        __syncthreads();
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    // cur = [[E^T, Xbar],[0, E^T]]
+    if (lane < 16) {
+        const int r = lane >> 2, c = lane & 3;
+        double v = 0.0;
+        for (int q = 0; q < 4; ++q) v += cur[r * 8 + q] * G[q * 4 + c];  // E^T G
+        Gdir_out[(size_t)b * 16 + lane] = v;
+    }
+    if (lane == 0) {
+        auto xb = [&](int r, int c) { return cur[r * 8 + 4 + c]; };
+        double db[P];
+        if (DIM == 2) {
+            db[0] = xb(0, 3);
+            db[1] = xb(1, 3);
+            db[2] = xb(1, 0) - xb(0, 1);
+        } else {
+            db[0] = xb(0, 3);
+            db[1] = xb(1, 3);
+            db[2] = xb(2, 3);
+            db[P - 3] = xb(2, 1) - xb(1, 2);
+            db[P - 2] = xb(0, 2) - xb(2, 0);
+            db[P - 1] = xb(1, 0) - xb(0, 1);
+        }
+        double A[P * P], lam[P];
+        for (int q = 0; q < P * P; ++q) A[q] = Amat[(size_t)b * 36 + q];
+        // forward took delta = 0 when A was not positive definite: no dependence then
+        chol_solve<P>(A, db, lam);
+        for (int q = 0; q < 6; ++q) lam_out[(size_t)b * 6 + q] = (q < P) ? lam[q] : 0.0;
+    }
+}
+
+// I7 backward, per-point part: dL/dweight and the point path of dL/dT_k.
+template <int DIM, int TYPE>
+__global__ __launch_bounds__(ACC_THREADS) void icp_bwd_point_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgt, int tgt_cols,
+    const float *__restrict__ weight, const float *__restrict__ Tk, const int32_t *__restrict__ active,
+    const int32_t *__restrict__ idx, const double *__restrict__ lam64, const double *__restrict__ delta64, int N,
+    int M, int loss, float k, float k2, float trim2, float *__restrict__ gw, double *__restrict__ pparts)
+{
+    constexpr int P = PointTerms<DIM, TYPE>::P;
+    constexpr int NR = PointTerms<DIM, TYPE>::NR;
+    constexpr int NP = npose(DIM);
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * ACC_THREADS + threadIdx.x;
+    double acc[NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) acc[a] = 0.0;
+    const bool act = active[b] != 0;
+
+    if (act && i < N) {
+        float T[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T[q] = Tk[(size_t)b * 16 + q];
+        float lam[P], dl[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            lam[q] = (float)lam64[(size_t)b * 6 + q];
+            dl[q] = (float)delta64[(size_t)b * 6 + q];
+        }
+        const int j = idx[(size_t)b * N + i];
+        const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
+        PointTerms<DIM, TYPE> t;
+        point_terms<DIM, TYPE>(t, T, src + ((size_t)b * N + i) * 3, tgt + ((size_t)b * M + j) * tgt_cols, omega,
+                               loss, k, k2, trim2);
+        float wbar = 0.f;
+        float ebar[NR];
+        float Jbar[NR][P];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                u += t.J[r][c] * lam[c];
+                v += t.J[r][c] * dl[c];
+            }
+            const float res = t.er[r] - v;
+            wbar += u * res;
+            ebar[r] = t.w * u;
+#pragma unroll
+            for (int c = 0; c < P; ++c) Jbar[r][c] = t.w * (res * lam[c] - u * dl[c]);
+        }
+        // w = (omega*keep)*rho
+        const float gomega = wbar * t.keep * t.rho;
+        const float rhobar = wbar * t.omega * t.keep;
+        float r2bar = 0.f;
+        if (loss == MMK_LOSS_CAUCHY) {
+            r2bar = rhobar * (-(t.rho * t.rho) / k2);
+        } else if (loss == MMK_LOSS_HUBER) {
+            if (sqrtf(t.r2) > k) r2bar = rhobar * (-t.rho / (2.f * t.r2));
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) ebar[r] += 2.f * t.er[r] * r2bar;
+        gw[(size_t)b * N + i] += gomega;
+
+        float pbar[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) pbar[c] = 0.f;
+        if (TYPE == MMK_ICP_PT2PT) {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) pbar[c] -= ebar[c % NR];
+            if (DIM == 2) {
+                pbar[1] -= Jbar[0][2];
+                pbar[0] += Jbar[NR - 1][2];
+            } else {
+                pbar[DIM - 1] += Jbar[0][P - 2];
+                pbar[1] -= Jbar[0][P - 1];
+                pbar[DIM - 1] -= Jbar[1 % NR][P - 3];
+                pbar[0] += Jbar[1 % NR][P - 1];
+                pbar[1] += Jbar[2 % NR][P - 3];
+                pbar[0] -= Jbar[2 % NR][P - 2];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) pbar[c] -= t.n[c] * ebar[0];
+            if (DIM == 2) {
+                pbar[0] += t.n[1] * Jbar[0][2];
+                pbar[1] -= t.n[0] * Jbar[0][2];
+            } else {
+                const float nx = t.n[0], ny = t.n[1], nz = t.n[DIM - 1];
+                const float j3 = Jbar[0][P - 3], j4 = Jbar[0][P - 2], j5 = Jbar[0][P - 1];
+                pbar[0] += -nz * j4 + ny * j5;
+                pbar[1] += nz * j3 - nx * j5;
+                pbar[DIM - 1] += -ny * j3 + nx * j4;
+            }
+        }
+        // p = R s + t
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) acc[r * DIM + c] = (double)pbar[r] * (double)t.s[c];
+            acc[DIM * DIM + r] = (double)pbar[r];
+        }
+    }
+
+    __shared__ double red[ACC_THREADS / 64][NP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) red[wv][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NP) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
+        pparts[((size_t)b * gridDim.x + blockIdx.x) * NP + threadIdx.x] = v;
+    }
+}
+
+__global__ void f32_to_f64_kernel(const float *in, double *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+template <int DIM>
+__global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *__restrict__ pparts, int nparts,
+                                 float *__restrict__ out)
+{
+    constexpr int NP = npose(DIM);
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 16) return;
+    double v = Gdir[(size_t)b * 16 + lane];
+    const int r = lane >> 2, c = lane & 3;
+    int slot = -1;
+    if (r < DIM && c < DIM) slot = r * DIM + c;
+    if (r < DIM && c == 3) slot = DIM * DIM + r;
+    if (slot >= 0)
+        for (int q = 0; q < nparts; ++q) v += pparts[((size_t)b * nparts + q) * NP + slot];
+    out[(size_t)b * 16 + lane] = (float)v;
+}
+
+// ------------------------------------------------------------------------------------------
+struct NNPlan {
+    int Mpad, ntiles, nsb, S, tiles_per_split, grid;
+};
+
+NNPlan nn_plan(int B, int N, int M)
+{
+    NNPlan pl;
+    pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
+    pl.ntiles = pl.Mpad / NN_TILE;
+    pl.nsb = (N + NN_THREADS * NN_P - 1) / (NN_THREADS * NN_P);
+    // enough waves to give every SIMD of the 256 CUs several to choose from
+    const int want_blocks = 1536;
+    int S = (want_blocks + B * pl.nsb - 1) / (B * pl.nsb);
+    S = std::max(1, std::min(S, std::min(pl.ntiles, 16)));
+    pl.tiles_per_split = (pl.ntiles + S - 1) / S;
+    pl.S = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    const int Bpad = (B + 7) / 8 * 8;
+    pl.grid = Bpad * pl.nsb * pl.S;
+    return pl;
+}
+
+int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
+              const NNPlan &pl, float *pd, int32_t *pi, hipStream_t st)
+{
+    if (dim == 2)
+        hipLaunchKernelGGL(nn_search_kernel<2>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
+                           pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
+    else
+        hipLaunchKernelGGL(nn_search_kernel<3>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
+                           pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+int check_params(const mmk_icp_params *p)
+{
+    MMK_REQUIRE(p != nullptr, "mmk_icp: params is NULL");
+    MMK_REQUIRE(p->B >= 1 && p->N >= 1 && p->M >= 1, "mmk_icp: B, N, M must be >= 1 (got %d, %d, %d)", p->B, p->N, p->M);
+    MMK_REQUIRE(p->dim == 2 || p->dim == 3, "mmk_icp: dim must be 2 or 3 (got %d)", p->dim);
+    MMK_REQUIRE(p->tgt_cols == 3 || p->tgt_cols == 6, "mmk_icp: target must have 3 or 6 columns (got %d)", p->tgt_cols);
+    MMK_REQUIRE(p->icp_type == MMK_ICP_PT2PT || p->icp_type == MMK_ICP_PT2PL, "mmk_icp: bad icp_type %d", p->icp_type);
+    MMK_REQUIRE(p->icp_type != MMK_ICP_PT2PL || p->tgt_cols == 6, "mmk_icp: pt2pl needs target normals (B,M,6)");
+    MMK_REQUIRE(p->loss >= MMK_LOSS_NONE && p->loss <= MMK_LOSS_HUBER, "mmk_icp: bad loss %d", p->loss);
+    MMK_REQUIRE(p->max_iter >= 1, "mmk_icp: max_iter must be >= 1");
+    MMK_REQUIRE(p->loss == MMK_LOSS_NONE || p->loss_k > 0.f, "mmk_icp: loss metric must be > 0");
+    return MMK_OK;
+}
+
+struct IcpWs {
+    float *tgtp;
+    float *pd;
+    int32_t *pi;
+    double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
+    double *G0, *G1;    // backward (B,16)
+    double *lam;        // backward (B,6)
+    int32_t *host_flag_dev;
+    size_t bytes;
+};
+
+IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
+{
+    const NNPlan pl = nn_plan(p->B, p->N, p->M);
+    const int nblk = (p->N + ACC_THREADS - 1) / ACC_THREADS;
+    mmk::Arena ar(ws, cap);
+    IcpWs w;
+    w.tgtp = ar.take<float>((size_t)p->B * p->dim * pl.Mpad);
+    w.pd = ar.take<float>((size_t)p->B * pl.S * p->N);
+    w.pi = ar.take<int32_t>((size_t)p->B * pl.S * p->N);
+    w.partials = ar.take<double>((size_t)p->B * nblk * 27);
+    w.G0 = ar.take<double>((size_t)p->B * 16);
+    w.G1 = ar.take<double>((size_t)p->B * 16);
+    w.lam = ar.take<double>((size_t)p->B * 6);
+    w.host_flag_dev = ar.take<int32_t>(16);
+    w.bytes = mmk::align_up(ar.off, 256);
+    return w;
+}
+
+template <int DIM, int TYPE>
+int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, const float *weight, float *T_hist,
+                int32_t *idx_hist, double *delta_hist, double *A_hist, int32_t *active_hist, const IcpWs &w,
+                int *iters_run, hipStream_t st)
+{
+    const int B = p->B, N = p->N, M = p->M;
+    const NNPlan pl = nn_plan(B, N, M);
+    const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
+    const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
+    int k_done = 0;
+    for (int it = 0; it < p->max_iter; ++it) {
+        const float *Tk = T_hist + (size_t)it * B * 16;
+        const int32_t *act = active_hist + (size_t)it * B;
+        int32_t *idx = idx_hist + (p->save_state ? (size_t)it * B * N : 0);
+        int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.pd, w.pi, st);
+        if (rc != MMK_OK) return rc;
+        hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
+                           p->tgt_cols, weight, Tk, act, w.pd, w.pi, pl.S, idx, N, M, p->loss, k, k2, trim2,
+                           w.partials);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(icp_solve_kernel<DIM>, dim3(B), dim3(64), 0, st, w.partials, nblk, Tk,
+                           T_hist + (size_t)(it + 1) * B * 16, delta_hist + (size_t)it * B * 6,
+                           A_hist + (size_t)it * B * 36, act, active_hist + (size_t)(it + 1) * B, p->tolerance);
+        MMK_LAUNCH_CHECK();
+        k_done = it + 1;
+        if (p->check_every > 0 && (k_done % p->check_every) == 0 && k_done < p->max_iter) {
+            static thread_local int32_t host_act[1 << 16];
+            MMK_REQUIRE(B <= (1 << 16), "mmk_icp_forward: check_every needs B <= 65536");
+            MMK_CHECK_HIP(hipMemcpyAsync(host_act, active_hist + (size_t)k_done * B, sizeof(int32_t) * B,
+                                         hipMemcpyDeviceToHost, st));
+            MMK_CHECK_HIP(hipStreamSynchronize(st));
+            bool any = false;
+            for (int b = 0; b < B; ++b) any = any || host_act[b] != 0;
+            if (!any) break;
+        }
+    }
+    // iterations that were skipped after an early stop: carry the pose forward
+    for (int it = k_done; it < p->max_iter; ++it) {
+        MMK_CHECK_HIP(hipMemcpyAsync(T_hist + (size_t)(it + 1) * B * 16, T_hist + (size_t)it * B * 16,
+                                     sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
+        MMK_CHECK_HIP(hipMemsetAsync(active_hist + (size_t)(it + 1) * B, 0, sizeof(int32_t) * B, st));
+        MMK_CHECK_HIP(hipMemsetAsync(delta_hist + (size_t)it * B * 6, 0, sizeof(double) * B * 6, st));
+    }
+    if (iters_run) *iters_run = k_done;
+    return MMK_OK;
+}
+
+template <int DIM, int TYPE>
+int run_backward(const mmk_icp_params *p, const float *src, const float *tgt, const float *weight,
+                 const int32_t *idx_hist, const float *T_hist, const double *delta_hist, const double *A_hist,
+                 const int32_t *active_hist, const float *grad_T, float *gw, float *grad_T_init, const IcpWs &w,
+                 hipStream_t st)
+{
+    const int B = p->B, N = p->N, M = p->M;
+    const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
+    const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
+    MMK_CHECK_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)B * N, st));
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3((B * 16 + 255) / 256), dim3(256), 0, st, grad_T, w.G0, B * 16);
+    MMK_LAUNCH_CHECK();
+    double *Gin = w.G0, *Gout = w.G1;
+    int nparts = 0;
+    for (int it = p->max_iter - 1; it >= 0; --it) {
+        const float *Tk = T_hist + (size_t)it * B * 16;
+        const int32_t *act = active_hist + (size_t)it * B;
+        hipLaunchKernelGGL(icp_bwd_pair_kernel<DIM>, dim3(B), dim3(64), 0, st, Gin, w.partials, nparts, Tk,
+                           delta_hist + (size_t)it * B * 6, A_hist + (size_t)it * B * 36, act, Gout, w.lam);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL((icp_bwd_point_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
+                           p->tgt_cols, weight, Tk, act, idx_hist + (size_t)it * B * N, w.lam,
+                           delta_hist + (size_t)it * B * 6, N, M, p->loss, k, k2, trim2, gw, w.partials);
+        MMK_LAUNCH_CHECK();
+        nparts = nblk;
+        double *t = Gin; Gin = Gout; Gout = t;
+    }
+    if (grad_T_init) {
+        hipLaunchKernelGGL(bwd_final_kernel<DIM>, dim3(B), dim3(64), 0, st, Gin, w.partials, nparts, grad_T_init);
+        MMK_LAUNCH_CHECK();
+    }
+    return MMK_OK;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" int32_t mmk_nn_padded_m(int32_t M) { return (int32_t)mmk::align_up((size_t)std::max(M, 1), NN_TILE); }
+
+extern "C" int mmk_pack_target(const float *target, int32_t B, int32_t M, int32_t tgt_cols, int32_t dim,
+                               float *target_planar, void *stream)
+{
+    MMK_REQUIRE(target && target_planar, "mmk_pack_target: NULL pointer");
+    MMK_REQUIRE(B >= 1 && M >= 1, "mmk_pack_target: B, M must be >= 1");
+    MMK_REQUIRE((dim == 2 || dim == 3) && tgt_cols >= dim, "mmk_pack_target: dim must be 2|3 and <= tgt_cols");
+    const int Mpad = mmk_nn_padded_m(M);
+    hipLaunchKernelGGL(pack_target_kernel, dim3(Mpad / 256, B), dim3(256), 0, (hipStream_t)stream, target, M, tgt_cols,
+                       dim, Mpad, target_planar);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" size_t mmk_nn_workspace_bytes(int32_t B, int32_t N, int32_t M, int32_t dim)
+{
+    (void)dim;
+    if (B < 1 || N < 1 || M < 1) return 0;
+    const NNPlan pl = nn_plan(B, N, M);
+    return mmk::align_up((size_t)B * pl.S * N * 4, 256) * 2 + 512;
+}
+
+extern "C" int mmk_nn_search(const float *source, const float *target_planar, const float *T, int32_t B, int32_t N,
+                             int32_t M, int32_t dim, int32_t *idx, float *d2, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    MMK_REQUIRE(source && target_planar && T && idx && d2, "mmk_nn_search: NULL pointer");
+    MMK_REQUIRE(B >= 1 && N >= 1 && M >= 1, "mmk_nn_search: B, N, M must be >= 1");
+    MMK_REQUIRE(dim == 2 || dim == 3, "mmk_nn_search: dim must be 2 or 3");
+    const NNPlan pl = nn_plan(B, N, M);
+    mmk::Arena ar(workspace, workspace_bytes);
+    float *pd = ar.take<float>((size_t)B * pl.S * N);
+    int32_t *pi = ar.take<int32_t>((size_t)B * pl.S * N);
+    if (!ar.ok() || workspace == nullptr) {
+        mmk::set_error("mmk_nn_search: workspace too small (%zu < %zu)", workspace_bytes, ar.off);
+        return MMK_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_nn(dim, source, target_planar, T, nullptr, B, N, pl, pd, pi, st);
+    if (rc != MMK_OK) return rc;
+    hipLaunchKernelGGL(nn_merge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, pd, pi, N, pl.S, idx, d2);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" size_t mmk_icp_workspace_bytes(const mmk_icp_params *p)
+{
+    if (check_params(p) != MMK_OK) return 0;
+    return carve(p, nullptr, 0).bytes;
+}
+
+extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, const float *target,
+                               const float *weight, const float *T_init, float *T_out, int32_t *idx_hist,
+                               float *T_hist, double *delta_hist, double *A_hist, int32_t *active_hist,
+                               void *workspace, size_t workspace_bytes, int *iters_run, void *stream)
+{
+    int rc = check_params(p);
+    if (rc != MMK_OK) return rc;
+    MMK_REQUIRE(source && target && T_init && T_out && idx_hist && T_hist && delta_hist && A_hist && active_hist,
+                "mmk_icp_forward: NULL pointer");
+    const IcpWs w = carve(p, workspace, workspace_bytes);
+    if (workspace == nullptr || w.bytes > workspace_bytes) {
+        mmk::set_error("mmk_icp_forward: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+        return MMK_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p->B;
+    rc = mmk_pack_target(target, B, p->M, p->tgt_cols, p->dim, w.tgtp, stream);
+    if (rc != MMK_OK) return rc;
+    MMK_CHECK_HIP(hipMemcpyAsync(T_hist, T_init, sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, active_hist, B, 1);
+    MMK_LAUNCH_CHECK();
+    if (p->dim == 2 && p->icp_type == MMK_ICP_PT2PT)
+        rc = run_forward<2, MMK_ICP_PT2PT>(p, source, target, weight, T_hist, idx_hist, delta_hist, A_hist, active_hist, w, iters_run, st);
+    else if (p->dim == 2)
+        rc = run_forward<2, MMK_ICP_PT2PL>(p, source, target, weight, T_hist, idx_hist, delta_hist, A_hist, active_hist, w, iters_run, st);
+    else if (p->icp_type == MMK_ICP_PT2PT)
+        rc = run_forward<3, MMK_ICP_PT2PT>(p, source, target, weight, T_hist, idx_hist, delta_hist, A_hist, active_hist, w, iters_run, st);
+    else
+        rc = run_forward<3, MMK_ICP_PT2PL>(p, source, target, weight, T_hist, idx_hist, delta_hist, A_hist, active_hist, w, iters_run, st);
+    if (rc != MMK_OK) return rc;
+    MMK_CHECK_HIP(hipMemcpyAsync(T_out, T_hist + (size_t)p->max_iter * B * 16, sizeof(float) * B * 16,
+                                 hipMemcpyDeviceToDevice, st));
+    return MMK_OK;
+}
+
+extern "C" int mmk_icp_backward(const mmk_icp_params *p, const float *source, const float *target,
+                                const float *weight, const int32_t *idx_hist, const float *T_hist,
+                                const double *delta_hist, const double *A_hist, const int32_t *active_hist,
+                                const float *grad_T, float *grad_weight, float *grad_T_init, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    int rc = check_params(p);
+    if (rc != MMK_OK) return rc;
+    MMK_REQUIRE(p->save_state, "mmk_icp_backward: forward must have run with save_state = 1");
+    MMK_REQUIRE(source && target && idx_hist && T_hist && delta_hist && A_hist && active_hist && grad_T && grad_weight,
+                "mmk_icp_backward: NULL pointer");
+    const IcpWs w = carve(p, workspace, workspace_bytes);
+    if (workspace == nullptr || w.bytes > workspace_bytes) {
+        mmk::set_error("mmk_icp_backward: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+        return MMK_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dim == 2 && p->icp_type == MMK_ICP_PT2PT)
+        return run_backward<2, MMK_ICP_PT2PT>(p, source, target, weight, idx_hist, T_hist, delta_hist, A_hist, active_hist, grad_T, grad_weight, grad_T_init, w, st);
+    if (p->dim == 2)
+        return run_backward<2, MMK_ICP_PT2PL>(p, source, target, weight, idx_hist, T_hist, delta_hist, A_hist, active_hist, grad_T, grad_weight, grad_T_init, w, st);
+    if (p->icp_type == MMK_ICP_PT2PT)
+        return run_backward<3, MMK_ICP_PT2PT>(p, source, target, weight, idx_hist, T_hist, delta_hist, A_hist, active_hist, grad_T, grad_weight, grad_T_init, w, st);
+    return run_backward<3, MMK_ICP_PT2PL>(p, source, target, weight, idx_hist, T_hist, delta_hist, A_hist, active_hist, grad_T, grad_weight, grad_T_init, w, st);
+}

@@ -1,0 +1,504 @@
+// Radar image operators of the hot path on gfx950 (HBM-bound byte/float streaming):
+// GO-CFAR, blob-centre extraction with stable compaction, polar -> Cartesian bilinear
+// resampling, bilinear weight gather / scatter-add, BEV rasterisation.
+// Semantics: /root/reference/mm_masking/radar_utils.py (line numbers per kernel);
+// CPU restatement: oracle/radar_ref.py; golden vectors: tests/golden/radar_*.npz.
+#include <math.h>
+
+#include "mmk_common.h"
+
+namespace {
+
+constexpr int RT = 256;  // threads per block for the row kernels
+
+// Block-wide exclusive scan of one double per thread (RT threads); returns the exclusive
+// prefix of `v`, *total gets the block sum.  `sm` holds RT/64 doubles.
+__device__ __forceinline__ double block_excl_scan(double v, double *sm, double *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sm[wv] = inc;
+    __syncthreads();
+    double base = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < RT / 64; ++w) {
+        if (w < wv) base += sm[w];
+        tot += sm[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ int block_excl_scan_i(int v, int *sm, int *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sm[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RT / 64; ++w) {
+        if (w < wv) base += sm[w];
+        tot += sm[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// R2 cfar_mask (radar_utils.py:29-69).  One block per azimuth row: the row is staged in
+// LDS, an fp64 prefix sum gives every 50-cell window sum exactly rounded to fp32, and the
+// mask row is written back coalesced: one read + one write of the image.
+__global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__ raw, int R, int w2, int guard,
+                                                       int mincol, int maxcol, float a_th, float b_th, int diff,
+                                                       float steep, float *__restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *cs = reinterpret_cast<double *>(smem);                 // R + 1
+    float *row = reinterpret_cast<float *>(cs + (R + 1));          // R
+    __shared__ double wsum[RT / 64];
+    const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * R;
+    for (int c = threadIdx.x; c < R; c += RT) row[c] = raw[base + c];
+    __syncthreads();
+    const int L = (R + RT - 1) / RT;
+    const int c0 = min(R, (int)threadIdx.x * L), c1 = min(R, c0 + L);
+    double s = 0.0;
+    for (int c = c0; c < c1; ++c) s += (double)row[c];
+    double tot;
+    double run = block_excl_scan(s, wsum, &tot);
+    for (int c = c0; c < c1; ++c) {
+        cs[c] = run;
+        run += (double)row[c];
+    }
+    if (threadIdx.x == RT - 1) cs[R] = tot;
+    __syncthreads();
+    for (int c = threadIdx.x; c < R; c += RT) {
+        float th = 1000.0f;
+        if (c >= mincol && c < maxcol) {
+            const float left = (float)(cs[c - guard] - cs[c - w2 - guard]);
+            const float right = (float)(cs[min(R, c + w2 + guard + 1)] - cs[min(R, c + guard + 1)]);
+            const float stat = fmaxf(left, right) / (float)w2;
+            th = a_th * stat + b_th;
+        }
+        const float x = row[c];
+        float m;
+        if (diff) {
+            m = 0.5f * tanhf(steep * (x - th) + 2.5f) + 0.5f;
+            m = (fabsf(m) > 0.99f) ? m : 0.0f;
+        } else {
+            m = (x > th) ? 1.0f : 0.0f;
+        }
+        mask[base + c] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// R3 + R4: mean_peaks_parallel_fast (radar_utils.py:167-185) + extract_pc (:71-106).
+__device__ __forceinline__ float peak_value(const float *__restrict__ mrow, int j, int R, float res, int diff,
+                                            float steep)
+{
+    // marker stored at column j (< R-1): arr[j]*z[j+1] + arr[j+1]*z[j]
+    const float a0 = (res * (float)j) * mrow[j];
+    const float a1 = (res * (float)(j + 1)) * mrow[j + 1];
+    float z0, z1;
+    if (diff) {
+        z0 = 1.0f - tanhf(steep * a0);
+        z1 = 1.0f - tanhf(steep * a1);
+    } else {
+        z0 = (a0 == 0.0f) ? 1.0f : 0.0f;
+        z1 = (a1 == 0.0f) ? 1.0f : 0.0f;
+    }
+    return a0 * z1 + a1 * z0;
+}
+
+__global__ __launch_bounds__(RT) void peaks_count_kernel(const float *__restrict__ mask, int R, float res, int diff,
+                                                         float steep, int32_t *__restrict__ row_count)
+{
+    __shared__ int sm[RT / 64];
+    const int rowid = blockIdx.y * gridDim.x + blockIdx.x;
+    const float *mrow = mask + (size_t)rowid * R;
+    int cnt = 0;
+    for (int j = threadIdx.x; j < R - 1; j += RT) cnt += (peak_value(mrow, j, R, res, diff, steep) != 0.0f) ? 1 : 0;
+    int tot;
+    block_excl_scan_i(cnt, sm, &tot);
+    if (threadIdx.x == 0) row_count[rowid] = tot;
+}
+
+__global__ __launch_bounds__(RT) void peaks_scan_kernel(const int32_t *__restrict__ row_count, int A,
+                                                        int32_t *__restrict__ row_off, int32_t *__restrict__ total)
+{
+    __shared__ int sm[RT / 64];
+    const int b = blockIdx.x;
+    const int L = (A + RT - 1) / RT;
+    const int a0 = min(A, (int)threadIdx.x * L), a1 = min(A, a0 + L);
+    int s = 0;
+    for (int a = a0; a < a1; ++a) s += row_count[b * A + a];
+    int tot;
+    int run = block_excl_scan_i(s, sm, &tot);
+    for (int a = a0; a < a1; ++a) {
+        row_off[b * A + a] = run;
+        run += row_count[b * A + a];
+    }
+    if (threadIdx.x == 0) total[b] = tot;
+}
+
+__global__ __launch_bounds__(RT) void peaks_emit_kernel(const float *__restrict__ mask, int R, float res, int diff,
+                                                        float steep, const int32_t *__restrict__ row_off, int cap,
+                                                        float *__restrict__ mval, int32_t *__restrict__ mrow_out)
+{
+    __shared__ int sm[RT / 64];
+    const int a = blockIdx.x, b = blockIdx.y, A = gridDim.x;
+    const int rowid = b * A + a;
+    const float *mrow = mask + (size_t)rowid * R;
+    int base = row_off[rowid];
+    for (int j0 = 0; j0 < R - 1; j0 += RT) {
+        const int j = j0 + threadIdx.x;
+        float v = 0.0f;
+        if (j < R - 1) v = peak_value(mrow, j, R, res, diff, steep);
+        const int f = (v != 0.0f) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_i(f, sm, &tot);
+        if (f) {
+            const int g = base + pos;
+            if (g < cap) {
+                mval[(size_t)b * cap + g] = v;
+                mrow_out[(size_t)b * cap + g] = a;
+            }
+        }
+        base += tot;
+    }
+}
+
+__global__ void peaks_pair_kernel(const float *__restrict__ mval, const int32_t *__restrict__ mrow, int cap,
+                                  const int32_t *__restrict__ total, const float *__restrict__ az,
+                                  const float *__restrict__ T_ab, int A, int max_pts, float *__restrict__ out_pc,
+                                  int32_t *__restrict__ out_count)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const int npts = total[b] / 2;
+    if (k == 0) out_count[b] = npts;
+    if (k >= max_pts) return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (k < npts && 2 * k + 1 < cap) {
+        const size_t m = (size_t)b * cap + 2 * k;
+        const float rho = (mval[m + 1] + mval[m]) / 2.0f;
+        const float phi = (az[b * A + mrow[m + 1]] + az[b * A + mrow[m]]) / 2.0f;
+        x = rho * cosf(phi);
+        y = rho * sinf(phi);
+        if (T_ab) {
+            const float *T = T_ab + (size_t)b * 16;
+            const float xx = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+            const float yy = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+            const float zz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+            x = xx; y = yy; z = zz;
+        }
+    }
+    float *o = out_pc + ((size_t)b * max_pts + k) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bilinear tap fetch with zero padding; `rows` > H means the image is wrap-padded by one
+// row at both ends (interpolate_crossover, radar_utils.py:317-319) without materialising it.
+__device__ __forceinline__ float tap_polar(const float *__restrict__ img, int A, int R, int yi, int xi, int wrap)
+{
+    const int rows = wrap ? A + 2 : A;
+    if (xi < 0 || xi >= R || yi < 0 || yi >= rows) return 0.0f;
+    int r = yi;
+    if (wrap) r = (yi == 0) ? (A - 1) : ((yi == A + 1) ? 0 : yi - 1);
+    return img[(size_t)r * R + xi];
+}
+
+// R5 radar_polar_to_cartesian_diff (radar_utils.py:258-336).  One thread per Cartesian
+// pixel; the batch item's azimuth table sits in LDS for the binary search (wobble fix).
+__global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restrict__ polar,
+                                                            const float *__restrict__ az,
+                                                            const float *__restrict__ rgrid,
+                                                            const float *__restrict__ agrid, int A, int R, int W,
+                                                            float res, float half_res, int wrap, int fix_wobble,
+                                                            float *__restrict__ cart)
+{
+    extern __shared__ float laz[];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < A; i += blockDim.x) laz[i] = az[(size_t)b * A + i];
+    __syncthreads();
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= W * W) return;
+    const float rng = rgrid[pix], ang = agrid[pix];
+    float u = (rng - half_res) / res;
+    float v;
+    if (fix_wobble) {
+        int lo = 0, hi = A;  // lower_bound: first i with laz[i] >= ang
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (laz[mid] < ang) lo = mid + 1; else hi = mid;
+        }
+        int c3 = lo;
+        if (c3 == A) c3 -= 1;
+        int c2 = c3 - 1;
+        if (c2 < 0) c2 += 1;
+        const float a3 = laz[c3], a2 = laz[c2];
+        const float df = ang - a3;
+        const float delta = ((df * ((df < 0.f) ? 1.f : 0.f)) * ((c3 > 0) ? 1.f : 0.f)) / ((a3 - a2) + 1e-14f);
+        v = (float)c3 + delta;
+    } else {
+        const float step = (laz[A - 1] - laz[0]) / (float)(A - 1);
+        v = (ang - laz[0]) / step;
+    }
+    if (u < 0.f) u = 0.f;
+    const int rows = wrap ? A + 2 : A;
+    if (wrap) v = v + 1.0f;
+    // normalise to [-1,1] and back exactly as F.grid_sample(align_corners=True) does
+    const float gx = u / (float)(R - 1) * 2.0f - 1.0f;
+    const float gy = v / (float)(rows - 1) * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(R - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(rows - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx = ix - x0, wy = iy - y0;
+    const float ex = 1.0f - wx, sy = 1.0f - wy;
+    const int xi = (int)x0, yi = (int)y0;
+    const float *img = polar + (size_t)b * A * R;
+    const float out = tap_polar(img, A, R, yi, xi, wrap) * (sy * ex) + tap_polar(img, A, R, yi, xi + 1, wrap) * (sy * wx) +
+                      tap_polar(img, A, R, yi + 1, xi, wrap) * (wy * ex) +
+                      tap_polar(img, A, R, yi + 1, xi + 1, wrap) * (wy * wx);
+    cart[(size_t)b * W * W + pix] = out;
+}
+
+// ------------------------------------------------------------------------------------------
+// R8 + R9: point_to_cart_idx(min_to_plus_1=True) (radar_utils.py:374-391) feeding the
+// bilinear sampler of extract_weights (:108-128).
+struct Taps {
+    int xi, yi;
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Taps weight_taps(const float *__restrict__ p, int H, int W, float cres)
+{
+    const float x = p[0], y = p[1];
+    const bool fake = (x == 0.0f) && (y == 0.0f);
+    const float gu = -x / cres;
+    const float gv = y / cres;
+    float gx = gv / (float)(W - 1) * 2.0f;
+    float gy = gu / (float)(W - 1) * 2.0f;
+    if (fake) {
+        gx = -100.0f;
+        gy = -100.0f;
+    }
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx = ix - x0, wy = iy - y0;
+    Taps t;
+    t.xi = (int)x0;
+    t.yi = (int)y0;
+    t.w00 = (1.0f - wy) * (1.0f - wx);
+    t.w01 = (1.0f - wy) * wx;
+    t.w10 = wy * (1.0f - wx);
+    t.w11 = wy * wx;
+    return t;
+}
+
+__global__ void sample_weights_fwd_kernel(const float *__restrict__ mask, const float *__restrict__ pc, int N,
+                                          int cols, int H, int W, float cres, float *__restrict__ out)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cres);
+    const float *m = mask + (size_t)b * H * W;
+    auto tap = [&](int yy, int xx) -> float {
+        return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? m[(size_t)yy * W + xx] : 0.0f;
+    };
+    out[(size_t)b * N + n] = tap(t.yi, t.xi) * t.w00 + tap(t.yi, t.xi + 1) * t.w01 + tap(t.yi + 1, t.xi) * t.w10 +
+                             tap(t.yi + 1, t.xi + 1) * t.w11;
+}
+
+__global__ void sample_weights_bwd_kernel(const float *__restrict__ gw, const float *__restrict__ pc, int N, int cols,
+                                          int H, int W, float cres, float *__restrict__ gmask)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cres);
+    const float g = gw[(size_t)b * N + n];
+    float *m = gmask + (size_t)b * H * W;
+    auto put = [&](int yy, int xx, float w) {
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H) atomicAdd(&m[(size_t)yy * W + xx], g * w);
+    };
+    put(t.yi, t.xi, t.w00);
+    put(t.yi, t.xi + 1, t.w01);
+    put(t.yi + 1, t.xi, t.w10);
+    put(t.yi + 1, t.xi + 1, t.w11);
+}
+
+// ------------------------------------------------------------------------------------------
+// R10 extract_bev_from_pts (radar_utils.py:142-165): idempotent stores of 1.0.
+__global__ void bev_raster_kernel(const float *__restrict__ pc, int M, int cols, int W, float cres,
+                                  float *__restrict__ bev)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= M) return;
+    const float *p = pc + ((size_t)b * M + j) * cols;
+    float iu = -p[0] / cres + (float)W / 2.0f;
+    float iv = p[1] / cres + (float)W / 2.0f;
+    const float mid = (float)(W / 2);
+    if (iu < 0.f || iu > (float)(W - 1)) iu = mid;
+    if (iv < 0.f || iv > (float)(W - 1)) iv = mid;
+    const int uf = (int)floorf(iu), uc = (int)ceilf(iu), vf = (int)floorf(iv), vc = (int)ceilf(iv);
+    float *o = bev + (size_t)b * W * W;
+    o[(size_t)uc * W + vf] = 1.0f;
+    o[(size_t)uc * W + vc] = 1.0f;
+    o[(size_t)uf * W + vf] = 1.0f;
+    o[(size_t)uf * W + vc] = 1.0f;
+}
+
+__global__ void bev_centre_kernel(float *__restrict__ bev, int B, int W)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) bev[(size_t)b * W * W + (size_t)(W / 2) * W + (W / 2)] = 0.0f;
+}
+
+struct PeakWs {
+    int32_t *row_count, *row_off, *total, *mrow;
+    float *mval;
+    int cap;
+    size_t bytes;
+};
+
+PeakWs carve_peaks(int B, int A, int max_pts, void *ws, size_t cap_bytes)
+{
+    mmk::Arena ar(ws, cap_bytes);
+    PeakWs w;
+    w.cap = 2 * max_pts;
+    w.row_count = ar.take<int32_t>((size_t)B * A);
+    w.row_off = ar.take<int32_t>((size_t)B * A);
+    w.total = ar.take<int32_t>((size_t)B);
+    w.mrow = ar.take<int32_t>((size_t)B * w.cap);
+    w.mval = ar.take<float>((size_t)B * w.cap);
+    w.bytes = mmk::align_up(ar.off, 256);
+    return w;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" int mmk_cfar_mask(const float *raw, int32_t B, int32_t A, int32_t R, int32_t w2, int32_t guard,
+                             int32_t mincol, int32_t maxcol, float a_thresh, float b_thresh, int32_t diff,
+                             float steep_fact, float *mask, void *stream)
+{
+    MMK_REQUIRE(raw && mask, "mmk_cfar_mask: NULL pointer");
+    MMK_REQUIRE(B >= 1 && A >= 1 && R >= 1, "mmk_cfar_mask: raw_scans must be 3D with non-empty dims");
+    MMK_REQUIRE(w2 >= 1 && guard >= 0, "mmk_cfar_mask: bad window (w2=%d guard=%d)", w2, guard);
+    MMK_REQUIRE(mincol >= w2 + guard && maxcol <= R, "mmk_cfar_mask: column range [%d,%d) outside the row", mincol, maxcol);
+    const size_t smem = (size_t)(R + 1) * sizeof(double) + (size_t)R * sizeof(float);
+    MMK_REQUIRE(smem <= 160 * 1024 - 64, "mmk_cfar_mask: R=%d does not fit the 160 KB LDS row buffer", R);
+    if (smem > 64 * 1024)
+        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)cfar_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(cfar_mask_kernel, dim3(A, B), dim3(RT), smem, (hipStream_t)stream, raw, R, w2, guard, mincol,
+                       maxcol, a_thresh, b_thresh, diff, steep_fact, mask);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" size_t mmk_extract_peaks_workspace_bytes(int32_t B, int32_t A, int32_t R, int32_t max_pts)
+{
+    (void)R;
+    if (B < 1 || A < 1 || max_pts < 1) return 0;
+    return carve_peaks(B, A, max_pts, nullptr, 0).bytes;
+}
+
+extern "C" int mmk_extract_peaks(const float *mask, int32_t B, int32_t A, int32_t R, float res, const float *azimuths,
+                                 const float *times, const float *T_ab, int32_t diff, float steep_fact,
+                                 int32_t max_pts, float *out_pc, int32_t *out_count, void *workspace,
+                                 size_t workspace_bytes, void *stream)
+{
+    (void)times;  // the reference averages the azimuth times too but drops them in pol_2_cart (radar_utils.py:99,187-195)
+    MMK_REQUIRE(mask && azimuths && out_pc && out_count, "mmk_extract_peaks: NULL pointer");
+    MMK_REQUIRE(B >= 1 && A >= 1 && R >= 2 && max_pts >= 1, "mmk_extract_peaks: bad shape");
+    const PeakWs w = carve_peaks(B, A, max_pts, workspace, workspace_bytes);
+    if (workspace == nullptr || w.bytes > workspace_bytes) {
+        mmk::set_error("mmk_extract_peaks: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+        return MMK_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(peaks_count_kernel, dim3(A, B), dim3(RT), 0, st, mask, R, res, diff, steep_fact, w.row_count);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(peaks_scan_kernel, dim3(B), dim3(RT), 0, st, w.row_count, A, w.row_off, w.total);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(peaks_emit_kernel, dim3(A, B), dim3(RT), 0, st, mask, R, res, diff, steep_fact, w.row_off, w.cap,
+                       w.mval, w.mrow);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(peaks_pair_kernel, dim3((max_pts + 255) / 256, B), dim3(256), 0, st, w.mval, w.mrow, w.cap,
+                       w.total, azimuths, T_ab, A, max_pts, out_pc, out_count);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_polar_to_cart(const float *polar, const float *azimuths, const float *range_grid,
+                                 const float *angle_grid, int32_t B, int32_t A, int32_t R, int32_t W,
+                                 float radar_resolution, int32_t interpolate_crossover, int32_t fix_wobble, float *cart,
+                                 void *stream)
+{
+    MMK_REQUIRE(polar && azimuths && range_grid && angle_grid && cart, "mmk_polar_to_cart: NULL pointer");
+    MMK_REQUIRE(B >= 1 && A >= 2 && R >= 2 && W >= 1, "mmk_polar_to_cart: bad shape");
+    MMK_REQUIRE((size_t)A * 4 <= 64 * 1024, "mmk_polar_to_cart: too many azimuths (%d)", A);
+    const float half_res = (float)((double)radar_resolution / 2.0);
+    hipLaunchKernelGGL(polar_to_cart_kernel, dim3((W * W + 255) / 256, B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
+                       polar, azimuths, range_grid, angle_grid, A, R, W, radar_resolution, half_res,
+                       interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_sample_weights_fwd(const float *mask, const float *pc, int32_t B, int32_t N, int32_t pc_cols,
+                                      int32_t H, int32_t W, float cart_resolution, float *weights, void *stream)
+{
+    MMK_REQUIRE(mask && pc && weights, "mmk_sample_weights_fwd: NULL pointer");
+    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2, "mmk_sample_weights_fwd: bad shape");
+    hipLaunchKernelGGL(sample_weights_fwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, mask, pc, N,
+                       pc_cols, H, W, cart_resolution, weights);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_sample_weights_bwd(const float *grad_weights, const float *pc, int32_t B, int32_t N, int32_t pc_cols,
+                                      int32_t H, int32_t W, float cart_resolution, float *grad_mask, void *stream)
+{
+    MMK_REQUIRE(grad_weights && pc && grad_mask, "mmk_sample_weights_bwd: NULL pointer");
+    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2, "mmk_sample_weights_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    MMK_CHECK_HIP(hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * H * W, st));
+    hipLaunchKernelGGL(sample_weights_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, grad_weights, pc, N, pc_cols,
+                       H, W, cart_resolution, grad_mask);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_bev_raster(const float *pc, int32_t B, int32_t M, int32_t pc_cols, int32_t W, float cart_resolution,
+                              float *bev, void *stream)
+{
+    MMK_REQUIRE(pc && bev, "mmk_bev_raster: NULL pointer");
+    MMK_REQUIRE(B >= 1 && M >= 1 && pc_cols >= 2 && W >= 2, "mmk_bev_raster: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    MMK_CHECK_HIP(hipMemsetAsync(bev, 0, sizeof(float) * (size_t)B * W * W, st));
+    hipLaunchKernelGGL(bev_raster_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, pc, M, pc_cols, W, cart_resolution,
+                       bev);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bev_centre_kernel, dim3((B + 255) / 256), dim3(256), 0, st, bev, B, W);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}

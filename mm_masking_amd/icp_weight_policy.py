@@ -1,0 +1,199 @@
+"""``LearnICPWeightPolicy`` — host-side mirror of the reference module
+``mm_masking/icp_weight_policy.py`` (same constructor ``params`` keys, same
+``forward``/``icp`` signatures and return values, same ``state_dict`` keys), with
+
+  * the mask U-Net's convolutions on PyTorch-ROCm (MIOpen, bf16 autocast +
+    channels-last by default) — the only MFMA consumer of the path,
+  * ``extract_weights`` and the differentiable ICP in hand-written HIP kernels
+    (radar_utils.py / dICP/ICP.py of this package -> libmmk_hip.so).
+
+Reference lines: constructor :25-102, conv_block :104-125, forward :127-275,
+icp :277-288.  The Neptune/matplotlib plotting block (:221-264) is observability
+SaaS and out of scope: ``neptune_run``, ``epoch`` and ``batch_idx`` are accepted
+and ignored.  The per-step ``torch.cuda.empty_cache()`` calls (:187,217) are not
+reproduced (they only force syncs).
+"""
+import torch
+import torch.nn as nn
+from torch.nn import ModuleList
+
+from .dICP.ICP import ICP
+from .radar_utils import extract_weights, form_cart_range_angle_grid, form_polar_range_grid
+
+
+def weights_init(m):
+    """icp_weight_policy.py:15-22."""
+    classname = m.__class__.__name__
+    if classname.find("Conv") != -1:
+        try:
+            nn.init.xavier_uniform_(m.weight.data)
+            nn.init.zeros_(m.bias)
+        except AttributeError:
+            print("Skipping initialization of ", classname)
+
+
+class LearnICPWeightPolicy(nn.Module):
+    def __init__(self, params):
+        super().__init__()
+        self.res = 0.0596
+
+        icp_type = params["icp_type"]
+        network_inputs = {"fft": params["fft_input"], "cfar": params["cfar_input"], "range": params["range_input"]}
+        network_input_type = params["network_input_type"]
+        device = params["device"]
+        max_iter = params["max_iter"]
+
+        self.use_ICP_4_train = params["loss_icp_rot_weight"] > 0.0 and params["loss_icp_trans_weight"] > 0.0
+
+        config_path = "../external/dICP/config/dICP_config.yaml"
+        self.ICP_alg = ICP(icp_type=icp_type, config_path=config_path, differentiable=True,
+                           max_iterations=max_iter, tolerance=1e-5)
+        self.ICP_alg_inference = ICP(icp_type=icp_type, config_path=config_path, differentiable=False,
+                                     max_iterations=50, tolerance=1e-5)
+        self.float_type = params["float_type"]
+        self.device = device
+        self.network_inputs = network_inputs
+        if network_input_type == "cartesian":
+            self.range_mask, _ = form_cart_range_angle_grid(device=device)
+        elif network_input_type == "polar":
+            self.range_mask = form_polar_range_grid(polar_resolution=self.res, device=device)
+
+        self.network_input_type = network_input_type
+        self.network_output_type = params["network_output_type"]
+        self.leaky = params["leaky"]
+        self.dropout = params["dropout"]
+        self.batch_norm = params["batch_norm"]
+        self.normalize_type = params["normalize"]
+        self.log_transform = params["log_transform"]
+        self.a_thres = params["a_thresh"]
+        self.b_thres = params["b_thresh"]
+        self.gt_eye = params["gt_eye"]
+        self.norm_weights = params["norm_weights"]
+
+        # optional keys (absent upstream): what the reference hard-codes in icp()
+        self.icp_loss_fn = params.get("icp_loss_fn", {"name": "cauchy", "metric": 1.0})
+        self.icp_trim_dist = params.get("icp_trim_dist", 5.0)
+        self.icp_dim = params.get("icp_dim", 2)
+        # conv compute dtype: bf16 MFMA through MIOpen on a HIP device, fp32 masters
+        self.amp_dtype = params.get("amp_dtype", torch.bfloat16)
+        self.channels_last = params.get("channels_last", True)
+
+        self.mean_num_pts = 0.0
+        self.max_w = 0.0
+        self.min_w = 0.0
+        self.mean_w = 0.0
+        self.mean_all_pts = 0.0
+
+        init_c_num = network_inputs["fft"] + network_inputs["cfar"] + network_inputs["range"]
+        enc_channels = [init_c_num, 8, 16, 32, 64, 128, 256]
+        dec_channels = [256, 128, 64, 32, 16, 8]
+        self.encoder = ModuleList([self.conv_block(enc_channels[i], enc_channels[i + 1], i)
+                                   for i in range(len(enc_channels) - 1)])
+        self.decoder = ModuleList([self.conv_block(dec_channels[i], dec_channels[i + 1])
+                                   for i in range(len(dec_channels) - 1)])
+        self.final_layer = nn.Sequential(nn.Conv2d(dec_channels[-1], 1, kernel_size=1), nn.Sigmoid())
+        if params["init_weights"]:
+            self.apply(weights_init)
+
+    def conv_block(self, in_channels, out_channels, i=0):
+        """icp_weight_policy.py:104-125 (module order fixes the state_dict keys)."""
+        relu_layer = nn.LeakyReLU(0.1) if self.leaky else nn.ReLU()
+        modules = [nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1), relu_layer]
+        if self.batch_norm:
+            modules.append(nn.BatchNorm2d(out_channels))
+        modules.append(nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1))
+        modules.append(relu_layer)
+        if self.batch_norm:
+            modules.append(nn.BatchNorm2d(out_channels))
+        if self.dropout > 0.0:
+            modules.append(nn.Dropout(p=self.dropout))
+        if i > 0:
+            modules.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        return nn.Sequential(*modules)
+
+    # ------------------------------------------------------------------ U1-U4
+    def _network_input(self, fft_data, fft_cfar):
+        input_data = None
+        if self.network_inputs["fft"]:
+            input_data = fft_data.unsqueeze(1)
+        if self.network_inputs["cfar"]:
+            input_data = torch.cat([input_data, fft_cfar.unsqueeze(1)], dim=1)
+        if self.network_inputs["range"]:
+            rm = self.range_mask.to(input_data.device)
+            range_stack = rm.unsqueeze(0).expand(input_data.shape[0], -1, -1).unsqueeze(1)
+            input_data = torch.cat([input_data, range_stack], dim=1)
+        if self.log_transform:
+            input_data = torch.log(input_data + 1e-6)
+        chans = []
+        for c in range(input_data.shape[1]):
+            xc = input_data[:, c, :, :]
+            if "minmax" in self.normalize_type:
+                c_max, c_min = torch.max(xc), torch.min(xc)
+                xc = (xc - c_min) / (c_max - c_min)
+            elif "standardize" in self.normalize_type:
+                xc = (xc - torch.mean(xc)) / torch.std(xc)
+            chans.append(xc)
+        return torch.stack(chans, dim=1)
+
+    def _unet(self, input_data):
+        use_amp = input_data.is_cuda and self.amp_dtype is not None and self.amp_dtype != torch.float32
+        if self.channels_last and input_data.is_cuda:
+            input_data = input_data.contiguous(memory_format=torch.channels_last)
+        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=use_amp):
+            enc_layers = []
+            for layer in self.encoder:
+                enc_layers.append(input_data)
+                input_data = layer(input_data)
+            enc_layers.reverse()
+            for i, decoder_layer in enumerate(self.decoder):
+                skip_con = enc_layers[i]
+                input_data = nn.functional.interpolate(input_data, size=(skip_con.shape[2], skip_con.shape[3]),
+                                                       mode="bilinear", align_corners=True)
+                input_data = decoder_layer(input_data)
+                input_data = torch.cat([skip_con, input_data.to(skip_con.dtype)], dim=1)
+                input_data = decoder_layer(input_data)   # same weights applied twice (:178,182)
+            logits = self.final_layer[0](input_data)
+        return torch.sigmoid(logits.float()).squeeze(1)
+
+    def forward(self, batch_scan, batch_map, T_init, binary=False, override_mask=None, neptune_run=None, epoch=0,
+                batch_idx=0, mask_only=False):
+        fft_data = batch_scan["fft_data"].to(self.device)
+        fft_cfar = batch_scan["fft_cfar"].to(self.device)
+        scan_pc_raw = batch_scan["raw_pc"].to(self.device)
+        map_pc = batch_map["pc"].to(self.device)
+
+        if override_mask is None:
+            weight_mask = self._unet(self._network_input(fft_data, fft_cfar))
+        else:
+            weight_mask = override_mask.to(self.device)
+
+        if self.norm_weights:
+            weight_mask = weight_mask / torch.amax(weight_mask, dim=(1, 2), keepdim=True)
+        if binary:
+            weight_mask = torch.where(weight_mask > 0.5, 1.0, 0.0)
+        if mask_only:
+            return weight_mask
+
+        weights, diff_mean_num_non0, mean_num_non0, mean_w, max_w, min_w = extract_weights(weight_mask, scan_pc_raw)
+        self.mean_num_pts = mean_num_non0
+        self.max_w = max_w
+        self.min_w = min_w
+        self.mean_w = mean_w
+        non0_pts = (scan_pc_raw[:, :, 0] != 0.0) * (scan_pc_raw[:, :, 1] != 0.0)
+        self.mean_all_pts = torch.sum(non0_pts) / scan_pc_raw.shape[0]
+
+        scan_pc_filt = batch_scan["filtered_pc"].to(self.device)
+
+        if self.training and not self.use_ICP_4_train:
+            return T_init, weight_mask, diff_mean_num_non0
+
+        T_est = self.icp(scan_pc_filt, map_pc, T_init, weights)
+        return T_est, weight_mask, diff_mean_num_non0
+
+    def icp(self, scan_pc, map_pc, T_init, weights):
+        """icp_weight_policy.py:277-288 (loss_fn / trim_dist / dim hard-coded there;
+        overridable here through optional params keys)."""
+        alg = self.ICP_alg if self.training else self.ICP_alg_inference
+        icp_result = alg.icp(scan_pc, map_pc, T_init=T_init, weight=weights, trim_dist=self.icp_trim_dist,
+                             loss_fn=self.icp_loss_fn, dim=self.icp_dim)
+        return icp_result["T"]

@@ -1,0 +1,256 @@
+"""Trainer-side pieces of the hot path — mirror of the step-level functions of the
+reference driver ``mm_masking/train_icp_weights.py``:
+
+  train_policy            :22-69     one pass of zero_grad -> forward -> loss -> backward -> step
+  validate_policy         :71-177    inference path (no_grad, ICP_alg_inference)
+  eval_training_loss      :179-253   rot + trans + optional BCE mask losses
+  eval_validation_loss    :255-273
+  generate_baseline       :275-344   override-mask baselines (U-Net bypassed)
+  default_params          :354-410   the hard-coded ``params`` dict
+
+Neptune logging, figures and checkpoint upload (observability SaaS) are out of
+scope.  What the reference's Dataset/DataLoader does per item on the CPU
+(CFAR, polar -> Cartesian; icp_weight_dataset.py:182-200,336-352) is done here
+per batch on the GPU by ``prepare_batch`` — the synthetic pipeline has no vtr3
+point extractor, so the scan cloud comes from cfar_mask + extract_pc.
+"""
+import time
+
+import torch
+
+from . import radar_utils as ru
+from . import synthetic
+from .icp_weight_policy import LearnICPWeightPolicy
+
+
+def default_params(device=None):
+    """The reference's params (train_icp_weights.py:354-410) with BASELINE.json's
+    configuration of the ICP (pt2pl + Huber) as optional overrides."""
+    if device is None:
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    return {
+        "device": device, "float_type": torch.float32, "gt_eye": True, "pos_std": 2.0, "rot_std": 0.6,
+        "log_transform": False, "normalize": ["minmax"], "batch_size_train": 16, "batch_size_test": 32,
+        "icp_type": "pt2pt", "learning_rate": 1e-4, "leaky": False, "dropout": 0.05, "batch_norm": False,
+        "init_weights": True, "a_thresh": 1.0, "b_thresh": 0.09, "loss_icp_rot_weight": 1.0,
+        "loss_icp_trans_weight": 1.0, "loss_fft_mask_weight": 0.0, "loss_map_pts_mask_weight": 1.0,
+        "loss_cfar_mask_weight": 0.0, "num_pts_weight": 0.0, "optimizer": "adam", "icp_loss_only_iter": -1,
+        "max_iter": 10, "network_input_type": "cartesian", "network_output_type": "cartesian",
+        "binary_inference": False, "norm_weights": True, "fft_input": True, "cfar_input": False,
+        "range_input": False,
+    }
+
+
+def loss_weights_from(params):
+    """train_icp_weights.py:414-417."""
+    return {"icp_rot": params["loss_icp_rot_weight"], "icp_trans": params["loss_icp_trans_weight"],
+            "fft": params["loss_fft_mask_weight"], "mask_pts": params["loss_map_pts_mask_weight"],
+            "cfar": params["loss_cfar_mask_weight"], "num_pts": params["num_pts_weight"]}
+
+
+def prepare_batch(raw, params, max_loc_pts=5120, polar_res=0.0596):
+    """GPU counterpart of ICPWeightDataset.__getitem__ (icp_weight_dataset.py:323-362)
+    for synthetic input: GO-CFAR -> blob centres -> zero-padded scan cloud, and
+    polar -> Cartesian for the FFT and CFAR images.  ``raw`` holds device tensors
+    fft_polar (B,400,3360), azimuths (B,400), az_times (B,400), map_pc (B,M,6),
+    T_init, T_gt.  Returns the reference's dict-of-dicts batch."""
+    fft = raw["fft_polar"]
+    az = raw["azimuths"]
+    cfar = ru.cfar_mask(fft, polar_res, a_thresh=params["a_thresh"], b_thresh=params["b_thresh"], diff=False)
+    pc, _ = ru.extract_pc_padded(cfar, polar_res, az, raw["az_times"], max_loc_pts, diff=False)
+    fft_cart = ru.radar_polar_to_cartesian_diff(fft, az, polar_res)
+    cfar_cart = ru.radar_polar_to_cartesian_diff(cfar, az, polar_res)
+    loc_data = {"raw_pc": pc, "filtered_pc": pc, "fft_data": fft_cart, "fft_cfar": cfar_cart, "timestamp": 0}
+    map_data = {"pc": raw["map_pc"], "timestamp": 0}
+    T_data = {"T_ml_init": raw["T_init"], "T_ml_gt": raw["T_gt"]}
+    return {"loc_data": loc_data, "map_data": map_data, "transforms": T_data}
+
+
+def eval_training_loss(T_pred, mask, num_non0, batch_T_gt, batch_scan, batch_map, model, loss_weights=[],
+                       icp_loss_only_iter=0, gt_eye=True, epoch=0):
+    """train_icp_weights.py:179-253."""
+    mask_criterion = torch.nn.BCELoss()
+    dev, dt = T_pred.device, T_pred.dtype
+    loss_rot = torch.zeros(1, device=dev)
+    loss_trans = torch.zeros(1, device=dev)
+    loss_fft = torch.zeros(1, device=dev)
+    loss_mask_pts = torch.zeros(1, dtype=dt, device=dev)
+    loss_cfar = torch.zeros(1, dtype=dt, device=dev)
+    loss_num_pts = torch.zeros(1, dtype=dt, device=dev)
+
+    if loss_weights["icp_rot"] > 0.0 or loss_weights["icp_trans"] > 0.0:
+        eye = torch.eye(4, dtype=dt, device=dev)
+        if gt_eye:
+            xi_wedge = T_pred - eye
+        else:
+            xi_wedge = torch.matmul(T_pred, torch.inverse(batch_T_gt)) - eye
+        xi_r = xi_wedge[:, 0:2, 3]
+        xi_theta = xi_wedge[:, 1, 0].unsqueeze(-1)
+        loss_rot = torch.norm(xi_theta, dim=1).mean()
+        loss_trans = torch.norm(xi_r, dim=1).mean()
+    if icp_loss_only_iter <= 0 or (icp_loss_only_iter > 0 and epoch < icp_loss_only_iter) or \
+            (loss_weights["icp_rot"] <= 0 and loss_weights["icp_trans"] <= 0):
+        if loss_weights["fft"] > 0.0:
+            fft_data = batch_scan["fft_data"].to(mask.device)
+            mean_azimuth = torch.mean(fft_data, dim=(1, 2), keepdim=True)
+            fft_mask = torch.where(fft_data > 3.0 * mean_azimuth, torch.ones_like(fft_data), torch.zeros_like(fft_data))
+            loss_fft = mask_criterion(mask, fft_mask)
+        if loss_weights["cfar"] > 0.0:
+            loss_cfar = mask_criterion(mask, batch_scan["fft_cfar"].to(mask.device))
+        if loss_weights["mask_pts"] > 0.0:
+            map_pts_mask = ru.extract_bev_from_pts(batch_map["pc"].to(mask.device))
+            loss_mask_pts = mask_criterion(mask, map_pts_mask)
+        if loss_weights["num_pts"] > 0.0:
+            loss_num_pts = model.mean_all_pts - num_non0
+
+    loss = loss_weights["icp_rot"] * loss_rot + loss_weights["icp_trans"] * loss_trans \
+        + loss_weights["fft"] * loss_fft + loss_weights["mask_pts"] * loss_mask_pts \
+        + loss_weights["cfar"] * loss_cfar + loss_weights["num_pts"] * loss_num_pts
+    loss_components = {"rot": (loss_weights["icp_rot"] * loss_rot).detach(),
+                       "trans": (loss_weights["icp_trans"] * loss_trans).detach(),
+                       "fft": (loss_weights["fft"] * loss_fft).detach(),
+                       "mask_pts": (loss_weights["mask_pts"] * loss_mask_pts).detach(),
+                       "cfar": (loss_weights["cfar"] * loss_cfar).detach(),
+                       "num_pts": (loss_weights["num_pts"] * loss_num_pts).detach()}
+    return loss, loss_components
+
+
+def eval_validation_loss(T_pred, batch_T_gt, gt_eye=True):
+    """train_icp_weights.py:255-273 -> [||(theta,x,y)||, |theta|, ||(x,y)||] batch means."""
+    eye = torch.eye(4, dtype=T_pred.dtype, device=T_pred.device)
+    if gt_eye:
+        xi_wedge = T_pred - eye
+    else:
+        xi_wedge = torch.matmul(T_pred, torch.inverse(batch_T_gt)) - eye
+    xi_r = xi_wedge[:, 0:2, 3]
+    xi_theta = xi_wedge[:, 1, 0].unsqueeze(-1)
+    xi_stack = torch.cat((xi_theta, xi_r), dim=1)
+    return torch.hstack((torch.norm(xi_stack, dim=1).mean(), torch.norm(xi_theta, dim=1).mean(),
+                         torch.norm(xi_r, dim=1).mean()))
+
+
+def train_step(model, batch, opt, loss_weights, device, gt_eye=True, epoch=None, icp_loss_only_iter=0,
+               grad_sync=None):
+    """Body of the reference's batch loop (train_icp_weights.py:31-58).  ``grad_sync``
+    (optional callable) is where a data-parallel job all-reduces the gradients."""
+    batch_scan, batch_map, batch_T = batch["loc_data"], batch["map_data"], batch["transforms"]
+    batch_T_init = batch_T["T_ml_init"].to(device)
+    opt.zero_grad()
+    T_pred, mask, num_non0 = model(batch_scan, batch_map, batch_T_init)
+    batch_T_gt = batch_T["T_ml_gt"].to(device)
+    loss, loss_comp = eval_training_loss(T_pred, mask, num_non0, batch_T_gt, batch_scan, batch_map, model,
+                                         loss_weights=loss_weights, icp_loss_only_iter=icp_loss_only_iter,
+                                         gt_eye=gt_eye, epoch=epoch)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    opt.step()
+    return loss.detach(), loss_comp
+
+
+def train_policy(model, iterator, opt, loss_weights=[], device="cpu", epoch=None, icp_loss_only_iter=0, gt_eye=True,
+                 grad_sync=None):
+    """train_icp_weights.py:22-69."""
+    model.train()
+    loss_hist = 0.0
+    loss_comp_hist = []
+    n = 0
+    for batch in iterator:
+        loss, loss_comp = train_step(model, batch, opt, loss_weights, device, gt_eye=gt_eye, epoch=epoch,
+                                     icp_loss_only_iter=icp_loss_only_iter, grad_sync=grad_sync)
+        loss_hist += loss
+        loss_comp_hist.append(loss_comp)
+        n += 1
+    mean_loss = loss_hist / n
+    mean_loss_comp = {k: sum(d[k] for d in loss_comp_hist) / len(loss_comp_hist) for k in loss_comp_hist[0]}
+    return mean_loss, mean_loss_comp
+
+
+def validate_policy(model, iterator, gt_eye=True, device="cpu", binary=False, neptune_run=None, epoch=None):
+    """train_icp_weights.py:71-177 (without the Neptune figures)."""
+    model.eval()
+    val_acc = torch.zeros((1, 3), device=device)
+    mean_num_pc, mean_w, max_w, min_w = 0.0, 0.0, 0.0, 1000.0
+    n = 0
+    with torch.no_grad():
+        for batch in iterator:
+            batch_scan, batch_map, batch_T = batch["loc_data"], batch["map_data"], batch["transforms"]
+            batch_T_gt = batch_T["T_ml_gt"].to(device)
+            batch_T_init = batch_T["T_ml_init"].to(device)
+            T_pred, mask, _ = model(batch_scan, batch_map, batch_T_init, binary=binary)
+            mean_num_pc += model.mean_num_pts
+            max_w = model.max_w if model.max_w > max_w else max_w
+            min_w = model.min_w if model.min_w < min_w else min_w
+            mean_w += model.mean_w
+            val_acc += eval_validation_loss(T_pred, batch_T_gt, gt_eye=gt_eye)
+            n += 1
+    return val_acc / n, mean_num_pc / n, mean_w / n, max_w, min_w
+
+
+def generate_baseline(model, iterator, baseline_type="train", device="cpu",
+                      loss_weights={"icp": 1.0, "fft": 0.0, "mask_pts": 0.0, "cfar": 0.0}, binary=False, gt_eye=True):
+    """train_icp_weights.py:275-344: ICP with a fixed (non-learned) mask."""
+    model.train() if baseline_type == "train" else model.eval()
+    loss_init_hist, loss_ones_hist = [], []
+    with torch.no_grad():
+        for batch in iterator:
+            batch_scan, batch_map, batch_T = batch["loc_data"], batch["map_data"], batch["transforms"]
+            batch_T_gt = batch_T["T_ml_gt"].to(device)
+            batch_T_init = batch_T["T_ml_init"].to(device)
+            fft_data = batch_scan["fft_data"].to(device)
+            if loss_weights.get("cfar", 0.0) > 0.0:
+                ones_mask = batch_scan["fft_cfar"].to(device)
+            elif loss_weights.get("fft", 0.0) > 0.0:
+                mean_azimuth = torch.mean(fft_data, dim=(1, 2), keepdim=True)
+                ones_mask = torch.where(fft_data > 3.0 * mean_azimuth, torch.ones_like(fft_data),
+                                        torch.zeros_like(fft_data))
+            elif loss_weights.get("mask_pts", 0.0) > 0.0:
+                ones_mask = ru.extract_bev_from_pts(batch_map["pc"].to(device))
+            else:
+                ones_mask = torch.ones_like(fft_data)
+            T_pred_ones, mask_ones, num_non0 = model(batch_scan, batch_map, batch_T_init, binary=binary,
+                                                     override_mask=ones_mask)
+            if baseline_type == "train":
+                li, _ = eval_training_loss(batch_T_init, mask_ones, num_non0, batch_T_gt, batch_scan, batch_map, model,
+                                           loss_weights=loss_weights, gt_eye=gt_eye)
+                lo, _ = eval_training_loss(T_pred_ones, mask_ones, num_non0, batch_T_gt, batch_scan, batch_map, model,
+                                           loss_weights=loss_weights, gt_eye=gt_eye)
+            else:
+                li = eval_validation_loss(batch_T_init, batch_T_gt, gt_eye=gt_eye)[0]
+                lo = eval_validation_loss(T_pred_ones, batch_T_gt, gt_eye=gt_eye)[0]
+            loss_init_hist.append(float(li))
+            loss_ones_hist.append(float(lo))
+    return sum(loss_init_hist) / len(loss_init_hist), sum(loss_ones_hist) / len(loss_ones_hist)
+
+
+def make_optimizer(policy, params):
+    """train_icp_weights.py:462-465."""
+    if params["optimizer"] == "adam":
+        return torch.optim.Adam(policy.parameters(), lr=params["learning_rate"])
+    return torch.optim.SGD(policy.parameters(), lr=params["learning_rate"], nesterov=True, momentum=1.0)
+
+
+class SyntheticIterator:
+    """Stands in for DataLoader(ICPWeightDataset): yields ``n_batches`` prepared
+    batches of ``batch_size`` pairs; pair indices are strided by world size so
+    that ranks draw disjoint pairs of one seeded stream."""
+
+    def __init__(self, params, batch_size, n_batches, rank=0, world_size=1, dataset_type="train", max_loc_pts=5120,
+                 m_valid=20000, m_pad=20480, start=0):
+        self.params, self.bs, self.nb = params, batch_size, n_batches
+        self.rank, self.ws, self.kind = rank, world_size, dataset_type
+        self.max_loc_pts, self.m_valid, self.m_pad, self.start = max_loc_pts, m_valid, m_pad, start
+
+    def __len__(self):
+        return self.nb
+
+    def raw_batch(self, i):
+        first = self.start + i * self.bs * self.ws
+        idx = [first + self.rank + j * self.ws for j in range(self.bs)]
+        return synthetic.make_batch(idx, device=self.params["device"], m_valid=self.m_valid, m_pad=self.m_pad,
+                                    dataset_type=self.kind, pos_std=self.params["pos_std"],
+                                    rot_std=self.params["rot_std"])
+
+    def __iter__(self):
+        for i in range(self.nb):
+            yield prepare_batch(self.raw_batch(i), self.params, self.max_loc_pts)

@@ -34,7 +34,8 @@ iterations):
         pt2pt rows G = [I | -[p]x]; pt2pl row J = n^T G, rotational part
         fl(fl(a*b) - fl(c*d));  wJ = w*J (fp32)
   per pair, fp64
-        A = sum_i sum_rows wJ^T J   (exact fp64 products of fp32 values)
+        A = sum_i sum_rows wJ^T J   (exact fp64 products of fp32 values; upper
+                                     triangle computed, mirrored to the lower)
         b = sum_i sum_rows wJ^T e
     I5  delta = A^-1 b  (Cholesky; not positive definite -> delta = 0)
     I6  T_{k+1} = fp32( Exp(delta) @ fp64(T_k) ); a pair freezes once
@@ -178,6 +179,8 @@ def normal_equations(J, e, w):
     wJ = w[..., None, None] * J
     A = torch.einsum("bnrp,bnrq->bpq", wJ.double(), J.double())
     b = torch.einsum("bnrp,bnr->bp", wJ.double(), e.double())
+    # the upper triangle is normative; mirror it so that A is exactly symmetric
+    A = torch.triu(A) + torch.triu(A, 1).transpose(1, 2)
     return A, b
 
 

@@ -1,0 +1,285 @@
+"""Parity of the HIP differentiable ICP (through the C ABI) with the oracle.
+Bit-exact for correspondence indices; pose within 1e-3 m / 1e-4 rad (BASELINE.json
+north_star; in practice ~1e-6); gradients within 2e-3 relative of autograd through
+the CPU restatement."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from mm_masking_amd import _lib, synthetic
+from mm_masking_amd.dICP.ICP import ICP
+from oracle import _clib, dicp_ref
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _nn_gpu(src, tgt, T, dim):
+    L = _lib.lib()
+    B, N, _ = src.shape
+    M = tgt.shape[1]
+    s = torch.from_numpy(src).to(DEV)
+    t = torch.from_numpy(tgt).to(DEV)
+    Tt = torch.from_numpy(T.reshape(B, 16)).to(DEV)
+    Mpad = L.mmk_nn_padded_m(M)
+    planar = torch.empty(B, dim, Mpad, dtype=torch.float32, device=DEV)
+    _lib.check(L.mmk_pack_target(_lib.ptr(t), B, M, t.shape[2], dim, _lib.ptr(planar), _lib.stream_ptr(DEV)))
+    ws = torch.empty(L.mmk_nn_workspace_bytes(B, N, M, dim), dtype=torch.uint8, device=DEV)
+    idx = torch.empty(B, N, dtype=torch.int32, device=DEV)
+    d2 = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    _lib.check(L.mmk_nn_search(_lib.ptr(s), _lib.ptr(planar), _lib.ptr(Tt), B, N, M, dim, _lib.ptr(idx), _lib.ptr(d2),
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV)))
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), d2.cpu().numpy()
+
+
+def _rand_T(rng, B, dim):
+    T = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    for b in range(B):
+        xi = np.zeros(6)
+        xi[:2] = rng.uniform(-2, 2, 2)
+        xi[5] = rng.uniform(-0.6, 0.6)
+        if dim == 3:
+            xi[2] = rng.uniform(-0.5, 0.5)
+            xi[3:5] = rng.uniform(-0.1, 0.1, 2)
+        T[b] = synthetic.se3_exp(xi).astype(np.float32)
+    return T
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (2, 513, 1025), (3, 1000, 3000), (1, 1024, 1024), (9, 300, 2049)])
+def test_nn_bit_exact(dim, B, N, M):
+    rng = np.random.default_rng(B * 1000 + N + M + dim)
+    src = rng.uniform(-60, 60, (B, N, 3)).astype(np.float32)
+    tgt = rng.uniform(-60, 60, (B, M, 6)).astype(np.float32)
+    # exact duplicates in the target: ties must resolve to the lowest index
+    if M > 10:
+        tgt[:, M // 2] = tgt[:, 3]
+        tgt[:, M - 1] = tgt[:, 7]
+        src[:, 0] = tgt[:, 3, :3]
+    T = _rand_T(rng, B, dim)
+    idx, d2 = _nn_gpu(src, tgt, T, dim)
+    p = _clib.transform(src, T, dim)
+    idx_ref, d2_ref = _clib.nn_search(p, np.ascontiguousarray(tgt[:, :, :dim]))
+    np.testing.assert_array_equal(idx, idx_ref)
+    np.testing.assert_array_equal(d2, d2_ref)
+
+
+def test_nn_padded_targets_and_sources():
+    rng = np.random.default_rng(5)
+    B, N, M = 2, 700, 1500
+    src = np.zeros((B, N, 3), np.float32)
+    src[:, :500] = rng.uniform(-50, 50, (B, 500, 3))
+    tgt = np.full((B, M, 6), 1000.0, np.float32)
+    tgt[:, :1200] = rng.uniform(-50, 50, (B, 1200, 6))
+    T = _rand_T(rng, B, 2)
+    idx, d2 = _nn_gpu(src, tgt, T, 2)
+    idx_ref, d2_ref = _clib.nn_search(_clib.transform(src, T, 2), np.ascontiguousarray(tgt[:, :, :2]))
+    np.testing.assert_array_equal(idx, idx_ref)
+    np.testing.assert_array_equal(d2, d2_ref)
+    assert idx.max() < 1200
+
+
+def _pair_batch(B, n, m, dim, pad_n=0, pad_m=0, seed=0, with_normals=True):
+    S, Tg, Tt = [], [], []
+    for b in range(B):
+        s, t, T = synthetic.simple_cloud_pair(seed + b, n, m, dim=dim, pad_n=pad_n, pad_m=pad_m,
+                                              with_normals=with_normals, yaw=0.1 + 0.05 * b, trans=(0.6, -0.4 + 0.1 * b, 0.1))
+        S.append(s), Tg.append(t), Tt.append(T)
+    return np.stack(S), np.stack(Tg), np.stack(Tt)
+
+
+CASES = [("pt2pt", "cauchy", 2), ("pt2pl", "huber", 2), ("pt2pt", "huber", 3), ("pt2pl", "cauchy", 3),
+         ("pt2pl", None, 2)]
+
+
+@pytest.mark.parametrize("icp_type,loss,dim", CASES)
+def test_icp_forward_matches_oracle(icp_type, loss, dim):
+    B, n, m = 3, 1500, 4000
+    src, tgt, T_true = _pair_batch(B, n, m, dim, pad_n=100, pad_m=96, seed=10 * dim)
+    rng = np.random.default_rng(1)
+    w = rng.uniform(0.1, 1.0, (B, n + 100)).astype(np.float32)
+    w[:, n:] = 0.0
+    loss_fn = None if loss is None else {"name": loss, "metric": 1.0}
+    K = 8
+    ref = dicp_ref.ICPRef(icp_type, differentiable=False, max_iterations=K, tolerance=1e-9)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.eye(4).repeat(B, 1, 1),
+                  weight=torch.from_numpy(w), trim_dist=5.0, loss_fn=loss_fn, dim=dim)
+    # run the GPU with save_state to read every iteration's correspondences
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-9)
+    wt = torch.from_numpy(w).to(DEV).requires_grad_(True)
+    T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=torch.eye(4, device=DEV).repeat(B, 1, 1),
+                weight=wt, trim_dist=5.0, loss_fn=loss_fn, dim=dim)["T"]
+    saved = T.grad_fn.saved_tensors
+    idx_hist, T_hist = saved[3].cpu().numpy(), saved[4].cpu().numpy().reshape(K + 1, B, 4, 4)
+    for k in range(out["num_iter"]):
+        np.testing.assert_array_equal(idx_hist[k], out["hist"]["idx"][k].numpy(), err_msg="iteration %d" % k)
+        np.testing.assert_allclose(T_hist[k + 1], out["hist"]["T"][k + 1].numpy(), atol=2e-6)
+    Tg = T.detach().cpu().numpy()
+    np.testing.assert_allclose(Tg, out["T"].numpy(), atol=2e-6)
+    # known answer: the clouds are copies related by T_true
+    if icp_type == "pt2pl" or dim == 2:
+        assert np.abs(Tg[:, :dim, 3] - T_true[:, :dim, 3]).max() < 0.05
+        assert np.abs(Tg[:, 1, 0] - T_true[:, 1, 0]).max() < 5e-3
+
+
+@pytest.mark.parametrize("icp_type,loss,dim", CASES[:4])
+def test_icp_backward_matches_autograd(icp_type, loss, dim):
+    B, n, m = 2, 900, 2500
+    src, tgt, _ = _pair_batch(B, n, m, dim, pad_n=60, seed=77 + dim)
+    rng = np.random.default_rng(2)
+    w0 = rng.uniform(0.2, 1.0, (B, n + 60)).astype(np.float32)
+    w0[:, n:] = 0.0
+    loss_fn = {"name": loss, "metric": 0.5}
+    K = 5
+    G = torch.from_numpy(rng.normal(size=(B, 4, 4)).astype(np.float32))
+    T0 = torch.from_numpy(_rand_T(rng, B, dim) * 0 + np.eye(4, dtype=np.float32))
+    T0[:, 0, 3] += 0.2
+
+    wr = torch.from_numpy(w0).requires_grad_(True)
+    T0r = T0.clone().requires_grad_(True)
+    ref = dicp_ref.ICPRef(icp_type, differentiable=True, max_iterations=K, tolerance=1e-9)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=T0r, weight=wr, trim_dist=3.0,
+                  loss_fn=loss_fn, dim=dim)
+    (out["T"] * G).sum().backward()
+
+    wg = torch.from_numpy(w0).to(DEV).requires_grad_(True)
+    T0g = T0.clone().to(DEV).requires_grad_(True)
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-9)
+    T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=T0g, weight=wg, trim_dist=3.0,
+                loss_fn=loss_fn, dim=dim)["T"]
+    (T * G.to(DEV)).sum().backward()
+    np.testing.assert_allclose(T.detach().cpu().numpy(), out["T"].detach().numpy(), atol=2e-6)
+    gw, gw_ref = wg.grad.cpu().numpy(), wr.grad.numpy()
+    scale = np.abs(gw_ref).max()
+    assert scale > 0
+    assert np.abs(gw - gw_ref).max() <= 2e-3 * scale, (np.abs(gw - gw_ref).max(), scale)
+    gT, gT_ref = T0g.grad.cpu().numpy(), T0r.grad.numpy()
+    assert np.abs(gT - gT_ref).max() <= 2e-3 * np.abs(gT_ref).max()
+
+
+def test_oracle_gradient_finite_difference():
+    """Pins the oracle's own gradient (fp64 restatement, fixed correspondences)."""
+    B, n, m = 1, 120, 400
+    src, tgt, _ = _pair_batch(B, n, m, 2, seed=5)
+    K = 3
+    ref32 = dicp_ref.ICPRef("pt2pl", True, K, 1e-12)
+    base = ref32.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.eye(4).repeat(B, 1, 1),
+                     weight=torch.ones(B, n), trim_dist=5.0, loss_fn={"name": "cauchy", "metric": 1.0}, dim=2)
+    fixed = base["hist"]["idx"]
+
+    def f(wv):
+        o = ref32.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.eye(4).repeat(B, 1, 1), weight=wv,
+                      trim_dist=5.0, loss_fn={"name": "cauchy", "metric": 1.0}, dim=2, dtype=torch.float64,
+                      fixed_idx=fixed)["T"]
+        return o[:, 0, 3].sum() + 2.0 * o[:, 1, 0].sum()
+
+    w = torch.ones(B, n, dtype=torch.float64, requires_grad=True)
+    f(w).backward()
+    g = w.grad.clone()
+    eps = 1e-6
+    for i in (0, 17, 63, 119):
+        wp = w.detach().clone(); wp[0, i] += eps
+        wm = w.detach().clone(); wm[0, i] -= eps
+        fd = (f(wp) - f(wm)).item() / (2 * eps)
+        assert abs(fd - g[0, i].item()) <= 1e-5 * max(1e-3, abs(fd)) + 1e-9
+
+
+def test_icp_invariances():
+    B, n, m = 2, 800, 2000
+    src, tgt, _ = _pair_batch(B, n, m, 2, seed=31)
+    s, t = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    w = torch.rand(B, n, device=DEV) + 0.1
+    icp = ICP("pt2pl", differentiable=False, max_iterations=6, tolerance=1e-9)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)
+    T1 = icp.icp(s, t, T_init=torch.eye(4, device=DEV).repeat(B, 1, 1), weight=w, **kw)["T"]
+    # weight scaling leaves the Gauss-Newton step unchanged
+    T2 = icp.icp(s, t, T_init=torch.eye(4, device=DEV).repeat(B, 1, 1), weight=4.0 * w, **kw)["T"]
+    assert (T1 - T2).abs().max().item() < 1e-5
+    # zero-weight padded source rows and target_pad_val target rows change nothing
+    sp = torch.cat([s, torch.zeros(B, 50, 3, device=DEV)], 1)
+    wp = torch.cat([w, torch.zeros(B, 50, device=DEV)], 1)
+    tp = torch.cat([t, torch.full((B, 77, 6), icp.target_pad_val, device=DEV)], 1)
+    T3 = icp.icp(sp, tp, T_init=torch.eye(4, device=DEV).repeat(B, 1, 1), weight=wp, **kw)["T"]
+    assert (T1 - T3).abs().max().item() < 1e-6
+    # run-to-run determinism (fixed reduction order, no float atomics in the ICP)
+    T4 = icp.icp(s, t, T_init=torch.eye(4, device=DEV).repeat(B, 1, 1), weight=w, **kw)["T"]
+    assert torch.equal(T1, T4)
+    # returns a dict with key 'T' on the caller's device, also for CPU inputs
+    T5 = icp.icp(s.cpu(), t.cpu(), T_init=torch.eye(4).repeat(B, 1, 1), weight=w.cpu(), **kw)["T"]
+    assert T5.device.type == "cpu" and (T5 - T1.cpu()).abs().max().item() == 0.0
+
+
+def test_icp_tolerance_freezes_pairs_and_early_exit():
+    B, n, m = 2, 600, 1500
+    src, tgt, T_true = _pair_batch(B, n, m, 2, seed=3)
+    src[1] = tgt[1, :n, :3]              # pair 1 starts converged (exact copy)
+    s, t = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    icp = ICP("pt2pt", differentiable=False, max_iterations=50, tolerance=1e-5)
+    T = icp.icp(s, t, T_init=torch.eye(4, device=DEV).repeat(B, 1, 1), trim_dist=5.0,
+                loss_fn={"name": "cauchy", "metric": 1.0}, dim=2)["T"]
+    assert icp.last_iterations < 50                     # stopped by the polled flags
+    act = icp.last_state["active"].cpu().numpy()
+    assert act[0].tolist() == [1, 1] and act[1, 1] == 0   # pair 1 froze after its first (zero) step
+    ref = dicp_ref.ICPRef("pt2pt", False, 50, 1e-5)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.eye(4).repeat(B, 1, 1), trim_dist=5.0,
+                  loss_fn={"name": "cauchy", "metric": 1.0}, dim=2)
+    np.testing.assert_allclose(T.cpu().numpy(), out["T"].numpy(), atol=2e-6)
+    assert np.abs(T.cpu().numpy()[0, :2, 3] - T_true[0, :2, 3]).max() < 0.05
+
+
+def test_icp_error_behaviour():
+    icp = ICP("pt2pl", differentiable=False, max_iterations=2)
+    s = torch.zeros(1, 8, 3, device=DEV)
+    with pytest.raises(ValueError):
+        icp.icp(s, torch.zeros(1, 8, 3, device=DEV), dim=2)            # pt2pl without normals
+    with pytest.raises(ValueError):
+        icp.icp(s, torch.zeros(1, 8, 6, device=DEV), loss_fn={"name": "tukey", "metric": 1.0}, dim=2)
+    with pytest.raises(ValueError):
+        icp.icp(s, torch.zeros(1, 8, 6, device=DEV), dim=4)
+    p = _lib.IcpParams(B=1, N=8, M=8, tgt_cols=6, dim=2, icp_type=1, loss=2, loss_k=1.0, trim_dist=5.0, tolerance=0.0,
+                       max_iter=2, save_state=0, check_every=0)
+    L = _lib.lib()
+    rc = L.mmk_icp_forward(ctypes.byref(p), *([ctypes.c_void_p(8)] * 10), ctypes.c_void_p(0), 0, None, ctypes.c_void_p(0))
+    assert rc == -3 and b"workspace" in L.mmk_last_error()
+    # degenerate geometry (all weights zero): delta = 0, pose unchanged
+    T0 = torch.eye(4, device=DEV).repeat(1, 1, 1)
+    T0[0, 0, 3] = 0.3
+    T = ICP("pt2pt", differentiable=False, max_iterations=3).icp(
+        torch.rand(1, 16, 3, device=DEV), torch.rand(1, 16, 6, device=DEV), T_init=T0, weight=torch.zeros(1, 16, device=DEV),
+        dim=2)["T"]
+    assert torch.equal(T, T0)
+
+
+def test_config5_50k_fp32_gate():
+    """BASELINE.json configs[4]: 50k-point lidar submap, fp32 end to end, pose within
+    1e-3 m / 1e-4 rad of the CPU restatement, correspondences bit-exact."""
+    B = 2
+    raws = [synthetic.make_pair(100 + b, m_valid=50000, m_pad=50176) for b in range(B)]
+    tgt = np.stack([r["map_pc"] for r in raws])
+    rng = np.random.default_rng(0)
+    # scan = noisy sub-sample of the map seen from the perturbed pose
+    src = np.zeros((B, 5120, 3), np.float32)
+    T0 = np.stack([r["T_init"] for r in raws])
+    for b in range(B):
+        sel = rng.choice(50000, 4500, replace=False)
+        src[b, :4500, :2] = tgt[b, sel, :2] + rng.normal(0, 0.03, (4500, 2))
+    w = np.ones((B, 5120), np.float32)
+    w[:, 4500:] = 0
+    K = 10
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)
+    ref = dicp_ref.ICPRef("pt2pl", False, K, 1e-5)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.from_numpy(T0), weight=torch.from_numpy(w), **kw)
+    icp = ICP("pt2pl", differentiable=True, max_iterations=K, tolerance=1e-5)
+    wt = torch.from_numpy(w).to(DEV).requires_grad_(True)
+    T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=torch.from_numpy(T0).to(DEV), weight=wt, **kw)["T"]
+    idx_hist = T.grad_fn.saved_tensors[3].cpu().numpy()
+    for k in range(out["num_iter"]):
+        np.testing.assert_array_equal(idx_hist[k], out["hist"]["idx"][k].numpy())
+    Tg, Tr = T.detach().cpu().numpy(), out["T"].numpy()
+    assert np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max() <= 1e-3
+    assert np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max() <= 1e-4
+    # and the ICP actually localises: back to identity within a few cm
+    assert np.abs(Tg[:, :2, 3]).max() < 0.1 and np.abs(Tg[:, 1, 0]).max() < 5e-3
