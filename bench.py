@@ -1,0 +1,219 @@
+"""Benchmark of the hot path: scan-pairs/s through one full training step
+(GO-CFAR -> peak extraction -> polar->Cartesian -> mask U-Net (bf16) -> weight
+sampling -> 10-iteration point-to-plane Huber dICP -> loss -> backward -> Adam) on
+synthetic 400x3360 radar scans against 20k-point lidar submaps.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Prints ONE JSON line on rank 0 (contract: task prompt / DESIGN.md §6):
+  value      = whole-job scan-pairs/s, inputs resident in HBM before the timed region
+  roofline   = the brute-force NN kernel against the HBM roofline named by
+               BASELINE.json's north_star (plus the binding fp32 VALU roofline)
+  cpu_baseline = the oracle's CPU port of the same step on the host cores (rank 0, N=1)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
+N_PAD, M_VALID, M_PAD, DIM, ICP_ITERS = 5120, 20000, 20480, 2, 10
+
+
+def nn_algorithmic_bytes(B):
+    """SURVEY.md §8d / BASELINE.md §4: 4*d*N + 4*d*M + 8*N bytes per pair per launch."""
+    return B * (4 * DIM * N_PAD + 4 * DIM * M_PAD + 8 * N_PAD)
+
+
+def cpu_baseline(params_like, sample_pairs=2, timed_steps=2):
+    """The oracle's PyTorch-CPU port of the same train step (oracle/train_ref.py) on a
+    bounded sample: `sample_pairs` pairs per step, 1 warm-up + `timed_steps` steps."""
+    from mm_masking_amd import synthetic
+    from oracle import radar_ref, train_ref
+    torch.set_num_threads(os.cpu_count())
+    raw = synthetic.make_batch(list(range(sample_pairs)), device="cpu", m_valid=M_VALID, m_pad=M_PAD)
+    fft = raw["fft_polar"].numpy()
+    # CFAR / polar->Cartesian are outside the reference's step (cached by its Dataset):
+    cfar = radar_ref.cfar_mask(fft, 0.0596, diff=False)
+    pcs = radar_ref.extract_pc(cfar, 0.0596, raw["azimuths"].numpy(), raw["az_times"].numpy(), diff=False)
+    pc = np.zeros((sample_pairs, N_PAD, 3), np.float32)
+    for b, p in enumerate(pcs):
+        pc[b, :min(len(p), N_PAD)] = p[:N_PAD]
+    cart = radar_ref.radar_polar_to_cartesian_diff(fft, raw["azimuths"].numpy(), 0.0596)
+    batch = {"fft_data": torch.from_numpy(cart), "raw_pc": torch.from_numpy(pc), "filtered_pc": torch.from_numpy(pc),
+             "map_pc": raw["map_pc"], "T_init": raw["T_init"], "T_gt": raw["T_gt"]}
+    step = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn={"name": "huber", "metric": 1.0}, max_iter=ICP_ITERS,
+                                  dim=DIM, dropout=0.05)
+    step.step(batch)
+    t0 = time.time()
+    for _ in range(timed_steps):
+        step.step(batch)
+    dt = time.time() - t0
+    return {"value": sample_pairs * timed_steps / dt, "unit": "pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d timed steps of B=%d after 1 warm-up (fp32 U-Net + 10-iter pt2pl Huber ICP fwd+bwd + Adam; "
+                      "CFAR/polar->Cartesian outside the step as in the reference's cached Dataset), %.1f s"
+                      % (timed_steps, sample_pairs, dt)}
+
+
+def pose_parity(model, params, device, pairs=2):
+    """GPU dICP vs the CPU restatement on identical inputs (outside the timed region)."""
+    from mm_masking_amd import synthetic
+    from mm_masking_amd import train_icp_weights as trn
+    from mm_masking_amd.dICP.ICP import ICP
+    from oracle import dicp_ref
+    raw = synthetic.make_batch(list(range(1000, 1000 + pairs)), device=device, m_valid=M_VALID, m_pad=M_PAD)
+    batch = trn.prepare_batch(raw, params, max_loc_pts=N_PAD)
+    src = batch["loc_data"]["filtered_pc"]
+    w = torch.rand(src.shape[:2], device=device)
+    lf = {"name": "huber", "metric": 1.0}
+    icp = ICP("pt2pl", differentiable=True, max_iterations=ICP_ITERS, tolerance=1e-5)
+    wg = w.clone().requires_grad_(True)
+    T = icp.icp(src, raw["map_pc"], T_init=raw["T_init"], weight=wg, trim_dist=5.0, loss_fn=lf, dim=DIM)["T"]
+    idx = T.grad_fn.saved_tensors[3].cpu().numpy()
+    ref = dicp_ref.ICPRef("pt2pl", differentiable=False, max_iterations=ICP_ITERS, tolerance=1e-5)
+    out = ref.icp(src.cpu(), raw["map_pc"].cpu(), T_init=raw["T_init"].cpu(), weight=w.cpu(), trim_dist=5.0,
+                  loss_fn=lf, dim=DIM)
+    mism = sum(int((idx[k] != out["hist"]["idx"][k].numpy()).sum()) for k in range(out["num_iter"]))
+    Tg, Tr = T.detach().cpu().numpy(), out["T"].numpy()
+    return {"nn_idx_mismatches": mism, "max_trans_err_m": float(np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max()),
+            "max_rot_err_rad": float(np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max()),
+            "pairs": pairs, "iters": ICP_ITERS}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="scan pairs per GPU per step (BASELINE configs[2])")
+    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic batches kept resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is HIP kernels with no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mm_masking_amd import _lib, ddp, synthetic
+    from mm_masking_amd import train_icp_weights as trn
+    from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+    L = _lib.lib()
+
+    params = trn.default_params(device)
+    params.update({"icp_type": "pt2pl", "icp_loss_fn": {"name": "huber", "metric": 1.0}, "icp_dim": DIM,
+                   "max_iter": ICP_ITERS, "dropout": 0.05})
+    lw = trn.loss_weights_from(params)
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(params).to(device)
+    model.train()
+    opt = trn.make_optimizer(model, params)
+    sync = ddp.FlatGradSync(model) if world > 1 else None
+    if sync is not None:
+        sync.sync_params(0)
+
+    # synthetic input, resident in HBM before anything is timed; rank r owns pairs r::world
+    B = args.batch
+    raws = []
+    for i in range(max(1, args.distinct)):
+        idx = ddp.shard_indices(B * world, rank, world, start=i * B * world)
+        raws.append(synthetic.make_batch(idx, device=device, m_valid=M_VALID, m_pad=M_PAD))
+
+    def one_step(i):
+        batch = trn.prepare_batch(raws[i % len(raws)], params, max_loc_pts=N_PAD)
+        return trn.train_step(model, batch, opt, lw, device, grad_sync=sync)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    cap = args.steps * ICP_ITERS + 8
+    _lib.check(L.mmk_nn_profile_begin(cap))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ms = (ctypes.c_float * cap)()
+    n_rec = ctypes.c_int32(0)
+    _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
+    nn_ms = np.array(ms[:min(n_rec.value, cap)], dtype=np.float64)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        nn_avg_s = float(nn_ms.mean()) * 1e-3 if len(nn_ms) else float("nan")
+        alg_bytes = nn_algorithmic_bytes(B)
+        achieved = alg_bytes / nn_avg_s / 1e9
+        evals = B * N_PAD * M_PAD                  # distance evaluations per launch
+        traffic = None
+        tr_file = os.path.join(ROOT, "profiles", "nn_traffic.json")
+        if os.path.exists(tr_file):
+            traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
+        result = {
+            "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: train_icp_weights step fwd+bwd, batch=%d per GPU, 10 dICP "
+                                   "iters, point-to-plane Huber, dim=2; 400x3360 polar radar -> GO-CFAR + peaks + "
+                                   "polar->Cartesian 640x640 -> U-Net (bf16 convs, fp32 masters) -> dICP (fp32 points, "
+                                   "fp64 normal equations) -> rot+trans+mask_pts loss -> Adam" % B,
+                       "batch_per_gpu": B, "global_batch": B * world, "scan_pts_pad": N_PAD, "map_pts": M_VALID,
+                       "map_pts_pad": M_PAD, "icp_iters": ICP_ITERS, "parallelism": "dp%d" % world,
+                       "final_loss": float(loss)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "nn_search_kernel<2>", "launches_timed": int(len(nn_ms)),
+                         "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "north_star names the HBM roofline; brute force does %.3g distance evaluations per "
+                                 "launch over those bytes (~2.2 kFLOP/B), so the binding roofline is fp32 VALU" % evals,
+                         "valu": {"pair_evals_per_s": evals / nn_avg_s,
+                                  "achieved_tflops": evals * 6 / nn_avg_s / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                                  "frac": evals * 6 / nn_avg_s / 1e12 / VALU_PEAK_TFLOPS,
+                                  "flop_per_eval": 6}},
+        }
+        if world == 1 and not args.no_parity:
+            result["pose_parity_vs_cpu_restatement"] = pose_parity(model, params, device)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(params)
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

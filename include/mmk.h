@@ -105,6 +105,15 @@ int mmk_nn_search(const float *source /*B,N,3*/, const float *target_planar,
                   int32_t *idx, float *d2, void *workspace, size_t workspace_bytes,
                   void *stream);
 
+/* Measurement hook (bench.py): while enabled, every nn_search launch made by this
+ * process (inside mmk_icp_forward or mmk_nn_search) is bracketed by HIP events on its
+ * launch stream.  _end() waits for the recorded events and returns the per-launch
+ * durations in milliseconds (ms_out is a HOST array; n_out = launches seen).  Process-wide,
+ * not thread-safe: measurement only.  Nothing upstream corresponds to it (the reference
+ * times whole epochs, train_icp_weights.py:518-523).                                    */
+int mmk_nn_profile_begin(int32_t capacity);
+int mmk_nn_profile_end(float *ms_out /*host*/, int32_t max_out, int32_t *n_out /*host*/);
+
 /* ------------------------------------------------------------------ radar_utils.py
  * mmk_cfar_mask        <- cfar_mask                      radar_utils.py:29-69
  * mmk_extract_peaks    <- extract_pc (+mean_peaks_parallel_fast, pol_2_cart)

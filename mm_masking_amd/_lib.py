@@ -73,6 +73,8 @@ def _declare(lib):
         "mmk_pack_target": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_nn_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_nn_search": (ctypes.c_int, [c_vp, c_vp, c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp, sz, c_vp]),
+        "mmk_nn_profile_begin": (ctypes.c_int, [i32]),
+        "mmk_nn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(ctypes.c_int32)]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
         "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,

@@ -812,9 +812,20 @@ NNPlan nn_plan(int B, int N, int M)
     return pl;
 }
 
+// Optional in-library timing of the NN kernel (bench.py's roofline leg): a pool of HIP
+// event pairs recorded on the launch stream around each nn_search launch.
+struct NNProf {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t *ev = nullptr;  // 2 * cap
+};
+NNProf g_prof;
+
 int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
               const NNPlan &pl, float *pd, int32_t *pi, hipStream_t st)
 {
+    const bool rec = g_prof.on && g_prof.n < g_prof.cap;
+    if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
     if (dim == 2)
         hipLaunchKernelGGL(nn_search_kernel<2>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
                            pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
@@ -822,6 +833,10 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
         hipLaunchKernelGGL(nn_search_kernel<3>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
                            pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
     MMK_LAUNCH_CHECK();
+    if (rec) {
+        MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+        g_prof.n++;
+    }
     return MMK_OK;
 }
 
@@ -995,6 +1010,37 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     if (rc != MMK_OK) return rc;
     hipLaunchKernelGGL(nn_merge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, pd, pi, N, pl.S, idx, d2);
     MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_nn_profile_begin(int32_t capacity)
+{
+    MMK_REQUIRE(capacity >= 1 && capacity <= (1 << 20), "mmk_nn_profile_begin: bad capacity %d", capacity);
+    if (g_prof.cap < capacity) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev;
+        g_prof.ev = new hipEvent_t[2 * (size_t)capacity];
+        g_prof.cap = 0;
+        for (int i = 0; i < 2 * capacity; ++i) MMK_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
+        g_prof.cap = capacity;
+    }
+    g_prof.n = 0;
+    g_prof.on = true;
+    return MMK_OK;
+}
+
+extern "C" int mmk_nn_profile_end(float *ms_out, int32_t max_out, int32_t *n_out)
+{
+    MMK_REQUIRE(n_out != nullptr, "mmk_nn_profile_end: NULL n_out");
+    g_prof.on = false;
+    int n = g_prof.n;
+    if (n > max_out) n = max_out;
+    for (int i = 0; i < n; ++i) {
+        MMK_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        MMK_CHECK_HIP(hipEventElapsedTime(&ms_out[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    }
+    *n_out = g_prof.n;
+    g_prof.n = 0;
     return MMK_OK;
 }
 

@@ -7,10 +7,11 @@
   (gt_eye, train_icp_weights.py:366) and T_init = Exp(xi), xi = (x,y,0,0,0,yaw),
   x,y ~ U(-2,2) m, yaw ~ U(-0.6,0.6) rad (icp_weight_dataset.py:261-267).
 
-The world is 2-D: random wall segments and a few closed polygons inside a 150 m
-square.  The radar image holds a Gaussian blob where each azimuth ray meets a
-wall, range-decaying Rayleigh speckle, and a few ghost returns that have no
-lidar counterpart (what the mask network should learn to down-weight).  Pure
+The world is 2-D: random wall segments, a few closed polygons and a few hundred
+pole-like scatterers inside a 150 m square.  The radar image holds a Gaussian
+blob where each azimuth ray meets one of its first walls or a pole,
+range-decaying Rayleigh speckle, and a few ghost returns that have no lidar
+counterpart (what the mask network should learn to down-weight).  Pure
 numpy on the host; seed = 1234 + global pair index so that every rank of a
 data-parallel job draws its own pairs of the same stream.
 """
@@ -48,10 +49,10 @@ def se3_exp(xi):
 
 def _walls(rng, half=75.0):
     segs = []
-    for _ in range(rng.integers(20, 41)):
+    for _ in range(rng.integers(120, 181)):
         c = rng.uniform(-half, half, 2)
         ang = rng.uniform(0, np.pi)
-        L = rng.uniform(8.0, 45.0)
+        L = rng.uniform(4.0, 30.0)
         d = np.array([np.cos(ang), np.sin(ang)]) * L / 2
         segs.append(np.concatenate([c - d, c + d]))
     for _ in range(rng.integers(2, 5)):
@@ -69,17 +70,34 @@ def _walls(rng, half=75.0):
     return segs[np.linalg.norm(mid, axis=1) > 6.0]
 
 
-def _lidar(rng, segs, m_valid, m_pad, pad_val):
+def _poles(rng, half=75.0):
+    """Compact scatterers (poles, trunks): (K,2) positions, at least 6 m from the sensor."""
+    k = rng.integers(250, 451)
+    r = rng.uniform(6.0, half, k)
+    a = rng.uniform(0, 2 * np.pi, k)
+    return np.stack([r * np.cos(a), r * np.sin(a)], axis=1)
+
+
+def _lidar(rng, segs, poles, m_valid, m_pad, pad_val):
     lens = np.linalg.norm(segs[:, 2:] - segs[:, :2], axis=1)
-    which = rng.choice(len(segs), size=m_valid, p=lens / lens.sum())
-    s = rng.uniform(0, 1, m_valid)
+    m_pole = min(m_valid // 8, 12 * len(poles))
+    m_wall = m_valid - m_pole
+    which = rng.choice(len(segs), size=m_wall, p=lens / lens.sum())
+    s = rng.uniform(0, 1, m_wall)
     p0, p1 = segs[which, :2], segs[which, 2:]
-    xy = p0 + s[:, None] * (p1 - p0) + rng.normal(0, 0.02, (m_valid, 2))
+    xy = p0 + s[:, None] * (p1 - p0) + rng.normal(0, 0.02, (m_wall, 2))
     t = (p1 - p0) / lens[which, None]
     n = np.stack([-t[:, 1], t[:, 0]], axis=1)
     # normals face the sensor, as estimated lidar normals do
     flip = np.sum(n * xy, axis=1) > 0
     n[flip] *= -1
+    pw = rng.integers(0, len(poles), m_pole)
+    pxy = poles[pw] + rng.normal(0, 0.06, (m_pole, 2))
+    pn = -pxy / np.linalg.norm(pxy, axis=1, keepdims=True)
+    xy = np.concatenate([xy, pxy])
+    n = np.concatenate([n, pn])
+    perm = rng.permutation(m_valid)
+    xy, n = xy[perm], n[perm]
     pc = np.full((m_pad, 6), pad_val, dtype=np.float32)
     pc[:m_valid, 0:2] = xy
     pc[:m_valid, 2] = 0.0
@@ -88,12 +106,11 @@ def _lidar(rng, segs, m_valid, m_pad, pad_val):
     return pc
 
 
-def _radar(rng, segs, wobble=True):
+def _radar(rng, segs, poles, wobble=True):
     counts = np.round(np.arange(N_AZ) * (ENCODER / N_AZ)).astype(np.int64)
     if wobble:
         counts = np.sort(np.clip(counts + rng.integers(-1, 2, N_AZ), 0, ENCODER - 1))
-        counts = np.maximum.accumulate(counts + np.arange(N_AZ) * 0)  # keep ascending
-    az = (counts * (2 * np.pi / ENCODER)).astype(np.float32)
+        az = (counts * (2 * np.pi / ENCODER)).astype(np.float32)
     d = np.stack([np.cos(az), np.sin(az)], axis=1).astype(np.float64)          # (A,2)
     p0, e = segs[:, :2], segs[:, 2:] - segs[:, :2]                               # (S,2)
     # ray o + t d hits p0 + s e :  t = cross(p0, e) / cross(d, e), s = cross(p0, d) / cross(d, e)
@@ -115,11 +132,19 @@ def _radar(rng, segs, wobble=True):
 
     for a in range(N_AZ):
         amp = 1.0
-        for h in range(3):                     # the beam partially penetrates: first three walls
+        for h in range(min(8, t.shape[1])):    # the beam partially penetrates: first eight walls
             if not np.isfinite(t[a, h]):
                 break
             blob(a, t[a, h], rng.uniform(0.4, 0.9) * amp)
-            amp *= 0.75
+            amp *= 0.9
+    pr = np.linalg.norm(poles, axis=1)
+    pa = np.mod(np.arctan2(poles[:, 1], poles[:, 0]), 2 * np.pi)
+    pk = np.searchsorted(az, pa.astype(np.float32)) % N_AZ
+    for k in range(len(poles)):                # a pole lights up one or two neighbouring azimuths
+        if pr[k] < (N_RANGE - 40) * POLAR_RES:
+            blob(int(pk[k]), pr[k], rng.uniform(0.4, 0.9))
+            if rng.uniform() < 0.5:
+                blob(int((pk[k] + 1) % N_AZ), pr[k], rng.uniform(0.3, 0.7))
     for _ in range(rng.integers(3, 9)):        # ghosts / multipath: no lidar counterpart
         a0 = rng.integers(0, N_AZ)
         r = rng.uniform(8.0, 70.0)
@@ -134,8 +159,9 @@ def make_pair(index, m_valid=20000, m_pad=20480, pad_val=1000.0, dataset_type="t
     """One synthetic scan pair (numpy)."""
     rng = np.random.default_rng(BASE_SEED + int(index))
     segs = _walls(rng)
-    map_pc = _lidar(rng, segs, m_valid, m_pad, pad_val)
-    fft, az, times = _radar(rng, segs, wobble=wobble)
+    poles = _poles(rng)
+    map_pc = _lidar(rng, segs, poles, m_valid, m_pad, pad_val)
+    fft, az, times = _radar(rng, segs, poles, wobble=wobble)
     if dataset_type == "train":
         xi = np.zeros(6)
         xi[0:2] = pos_std * rng.uniform(-1, 1, 2)

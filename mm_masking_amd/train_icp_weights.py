@@ -135,7 +135,10 @@ def train_step(model, batch, opt, loss_weights, device, gt_eye=True, epoch=None,
     (optional callable) is where a data-parallel job all-reduces the gradients."""
     batch_scan, batch_map, batch_T = batch["loc_data"], batch["map_data"], batch["transforms"]
     batch_T_init = batch_T["T_ml_init"].to(device)
-    opt.zero_grad()
+    if grad_sync is not None and hasattr(grad_sync, "zero_grad"):
+        grad_sync.zero_grad()           # keeps the flat gradient buffer attached
+    else:
+        opt.zero_grad()
     T_pred, mask, num_non0 = model(batch_scan, batch_map, batch_T_init)
     batch_T_gt = batch_T["T_ml_gt"].to(device)
     loss, loss_comp = eval_training_loss(T_pred, mask, num_non0, batch_T_gt, batch_scan, batch_map, model,

@@ -1,0 +1,150 @@
+"""The policy module and the training step on the GPU: U-Net parity with the golden
+vectors of the reference module (fp32) and with the bf16 MFMA path within bf16
+tolerance; reference call signatures; one full train step against the CPU port."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mm_masking_amd import synthetic
+from mm_masking_amd import train_icp_weights as trn
+from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+from oracle import train_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _params(**over):
+    p = trn.default_params(DEV)
+    p.update({"dropout": 0.0})
+    p.update(over)
+    return p
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unet_golden_fp32(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "unet.npz"), allow_pickle=False)
+    over = {"amp_dtype": torch.float32}
+    if tag == "b":
+        over.update({"cfar_input": True, "range_input": True, "leaky": True, "normalize": ["standardize"],
+                     "log_transform": True})
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(_params(**over)).to(DEV)
+    model.train()
+    names = [str(n) for n in g["names_" + tag]]
+    sd = model.state_dict()
+    assert list(sd.keys()) == names                                    # checkpoint compatibility
+    assert [str(tuple(sd[k].shape)) for k in names] == [str(s) for s in g["shapes_" + tag]]
+    np.testing.assert_allclose([sd[k].double().sum().item() for k in names], g["psum_" + tag], atol=1e-6)
+    if tag == "b":
+        model.range_mask = torch.from_numpy(g["range_b"]).to(DEV)
+    scan = {"fft_data": torch.from_numpy(g["x_" + tag]), "fft_cfar": torch.from_numpy(g["cfar_" + tag]),
+            "raw_pc": torch.zeros(2, 4, 3)}
+    m = model(scan, {"pc": torch.zeros(2, 4, 6)}, torch.eye(4).repeat(2, 1, 1), mask_only=True)
+    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_" + tag], atol=5e-5)
+    (m * torch.from_numpy(g["gsel_" + tag]).to(DEV)).sum().backward()
+    grads = dict(model.named_parameters())
+    ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
+    # MIOpen picks other fp32 conv algorithms (e.g. Winograd) than the CPU reference
+    np.testing.assert_allclose(ga, g["gabs_" + tag], rtol=2e-2, atol=1e-4)
+
+
+def test_unet_bf16_close_to_fp32():
+    torch.manual_seed(7)
+    m32 = LearnICPWeightPolicy(_params(amp_dtype=torch.float32)).to(DEV)
+    m16 = LearnICPWeightPolicy(_params()).to(DEV)
+    m16.load_state_dict(m32.state_dict())
+    x = torch.rand(2, 128, 128)
+    scan = {"fft_data": x, "fft_cfar": x, "raw_pc": torch.zeros(2, 4, 3)}
+    a = m32(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    b = m16(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    assert a.dtype == b.dtype == torch.float32
+    assert (a - b).abs().max().item() < 0.03          # bf16 conv stack, 33 layers deep
+
+
+def _small_batch(B=2, max_pts=2048, m_valid=3000):
+    raw = synthetic.make_batch(list(range(B)), device=DEV, m_valid=m_valid, m_pad=3072)
+    params = _params(icp_type="pt2pl", icp_loss_fn={"name": "huber", "metric": 1.0}, max_iter=5)
+    return raw, params, trn.prepare_batch(raw, params, max_loc_pts=max_pts)
+
+
+def test_forward_signature_and_modes():
+    raw, params, batch = _small_batch()
+    torch.manual_seed(0)
+    model = LearnICPWeightPolicy(params).to(DEV)
+    T0 = raw["T_init"]
+    model.train()
+    T, mask, nn0 = model(batch["loc_data"], batch["map_data"], T0)
+    assert T.shape == (2, 4, 4) and mask.shape == (2, 640, 640) and nn0.ndim == 0
+    assert T.requires_grad and float(mask.max()) == pytest.approx(1.0, abs=1e-6)
+    assert all(torch.is_tensor(v) for v in (model.mean_num_pts, model.max_w, model.min_w, model.mean_w, model.mean_all_pts))
+    # extra kwargs of the reference signature are accepted
+    model.eval()
+    with torch.no_grad():
+        Tb, maskb, _ = model(batch["loc_data"], batch["map_data"], T0, binary=True, neptune_run=None, epoch=3, batch_idx=1)
+        assert set(torch.unique(maskb).tolist()) <= {0.0, 1.0}
+        ones = torch.ones(2, 640, 640, device=DEV)
+        To, mo, _ = model(batch["loc_data"], batch["map_data"], T0, override_mask=ones)   # generate_baseline path
+        assert torch.equal(mo, ones)
+        # ICP with all-ones weights localises the synthetic pair: error shrinks
+        e0 = trn.eval_validation_loss(T0, raw["T_gt"])[0].item()
+        e1 = trn.eval_validation_loss(To, raw["T_gt"])[0].item()
+        assert e1 < 0.5 * e0
+    # training without the ICP loss returns the initial guess (icp_weight_policy.py:270-271)
+    p2 = dict(params)
+    p2["loss_icp_rot_weight"] = 0.0
+    m2 = LearnICPWeightPolicy(p2).to(DEV)
+    m2.train()
+    T2, _, _ = m2(batch["loc_data"], batch["map_data"], T0)
+    assert T2 is T0
+
+
+def test_train_step_matches_cpu_port():
+    """One full step (fp32 convs, no dropout) against the oracle's CPU port:
+    same loss, same mask, same pose, parameter gradients close."""
+    raw, params, batch = _small_batch(B=2, max_pts=2048)
+    params = dict(params, amp_dtype=torch.float32)
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(params).to(DEV)
+    model.train()
+    opt = trn.make_optimizer(model, params)
+    lw = trn.loss_weights_from(params)
+    opt.zero_grad()
+    T, mask, nn0 = model(batch["loc_data"], batch["map_data"], raw["T_init"])
+    loss, comp = trn.eval_training_loss(T, mask, nn0, raw["T_gt"], batch["loc_data"], batch["map_data"], model,
+                                        loss_weights=lw)
+    loss.backward()
+
+    ref = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn={"name": "huber", "metric": 1.0}, max_iter=5, dim=2,
+                                 dropout=0.0, seed=1234)
+    cb = {"fft_data": batch["loc_data"]["fft_data"].cpu(), "raw_pc": batch["loc_data"]["raw_pc"].cpu(),
+          "filtered_pc": batch["loc_data"]["filtered_pc"].cpu(), "map_pc": raw["map_pc"].cpu(),
+          "T_init": raw["T_init"].cpu(), "T_gt": raw["T_gt"].cpu()}
+    Tr, maskr, wr = ref.forward(cb, training=True)
+    lossr, _ = train_ref.eval_training_loss(Tr, maskr, None, cb["T_gt"], cb["fft_data"], None, cb["map_pc"], None, lw)
+    lossr.backward()
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), maskr.detach().numpy(), atol=2e-4)
+    np.testing.assert_allclose(T.detach().cpu().numpy(), Tr.detach().numpy(), atol=2e-3)
+    assert abs(loss.item() - lossr.item()) < 2e-3 * max(1.0, abs(lossr.item()))
+    gp = dict(model.named_parameters())
+    num = sum(((gp[k].grad.cpu() - ref.sd[k].grad) ** 2).sum().item() for k in ref.sd)
+    den = sum((ref.sd[k].grad ** 2).sum().item() for k in ref.sd)
+    assert num <= (0.05 ** 2) * den, (num, den)
+
+
+def test_training_reduces_loss_bf16():
+    raw, params, batch = _small_batch(B=2)
+    params = dict(params, learning_rate=1e-3)
+    torch.manual_seed(3)
+    model = LearnICPWeightPolicy(params).to(DEV)
+    opt = trn.make_optimizer(model, params)
+    lw = trn.loss_weights_from(params)
+    model.train()
+    losses = [trn.train_step(model, batch, opt, lw, DEV)[0].item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    val, npc, mw, mx, mn = trn.validate_policy(model, [batch], device=DEV)
+    assert val.shape == (1, 3) and torch.isfinite(val).all()
+    li, lo = trn.generate_baseline(model, [batch], baseline_type="val", device=DEV)
+    assert lo < li
