@@ -19,6 +19,23 @@ import os
 import sys
 import time
 
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup
+    CPU quota (a GPU box exposes every core of the host but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("MMK_BENCH_MAX_CORES", "16"))))
+
+
+# must be set before torch / libgomp start their thread pools
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -32,17 +49,26 @@ VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
 N_PAD, M_VALID, M_PAD, DIM, ICP_ITERS = 5120, 20000, 20480, 2, 10
 
 
+_T_START = time.time()
+
+
+def progress(msg):
+    """Progress lines on stderr (the JSON result is the only thing on stdout)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - _T_START, msg), file=sys.stderr, flush=True)
+
+
 def nn_algorithmic_bytes(B):
     """SURVEY.md §8d / BASELINE.md §4: 4*d*N + 4*d*M + 8*N bytes per pair per launch."""
     return B * (4 * DIM * N_PAD + 4 * DIM * M_PAD + 8 * N_PAD)
 
 
-def cpu_baseline(params_like, sample_pairs=2, timed_steps=2):
+def cpu_baseline(params_like, sample_pairs=4, timed_steps=3):
     """The oracle's PyTorch-CPU port of the same train step (oracle/train_ref.py) on a
     bounded sample: `sample_pairs` pairs per step, 1 warm-up + `timed_steps` steps."""
     from mm_masking_amd import synthetic
     from oracle import radar_ref, train_ref
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(usable_cores())
     raw = synthetic.make_batch(list(range(sample_pairs)), device="cpu", m_valid=M_VALID, m_pad=M_PAD)
     fft = raw["fft_polar"].numpy()
     # CFAR / polar->Cartesian are outside the reference's step (cached by its Dataset):
@@ -56,10 +82,12 @@ def cpu_baseline(params_like, sample_pairs=2, timed_steps=2):
              "map_pc": raw["map_pc"], "T_init": raw["T_init"], "T_gt": raw["T_gt"]}
     step = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn={"name": "huber", "metric": 1.0}, max_iter=ICP_ITERS,
                                   dim=DIM, dropout=0.05)
+    progress("cpu_baseline: warm-up step (%d threads)" % torch.get_num_threads())
     step.step(batch)
     t0 = time.time()
-    for _ in range(timed_steps):
+    for i in range(timed_steps):
         step.step(batch)
+        progress("cpu_baseline: timed step %d/%d done, %.1f s" % (i + 1, timed_steps, time.time() - t0))
     dt = time.time() - t0
     return {"value": sample_pairs * timed_steps / dt, "unit": "pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
@@ -86,7 +114,10 @@ def pose_parity(model, params, device, pairs=2):
     ref = dicp_ref.ICPRef("pt2pl", differentiable=False, max_iterations=ICP_ITERS, tolerance=1e-5)
     out = ref.icp(src.cpu(), raw["map_pc"].cpu(), T_init=raw["T_init"].cpu(), weight=w.cpu(), trim_dist=5.0,
                   loss_fn=lf, dim=DIM)
-    mism = sum(int((idx[k] != out["hist"]["idx"][k].numpy()).sum()) for k in range(out["num_iter"]))
+    mism = 0
+    for k in range(out["num_iter"]):
+        act = out["hist"]["active"][k].numpy()
+        mism += int((idx[k][act] != out["hist"]["idx"][k].numpy()[act]).sum())
     Tg, Tr = T.detach().cpu().numpy(), out["T"].numpy()
     return {"nn_idx_mismatches": mism, "max_trans_err_m": float(np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max()),
             "max_rot_err_rad": float(np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max()),
@@ -137,6 +168,7 @@ def main():
 
     # synthetic input, resident in HBM before anything is timed; rank r owns pairs r::world
     B = args.batch
+    progress("generating %d synthetic pairs per rank" % (B * max(1, args.distinct)))
     raws = []
     for i in range(max(1, args.distinct)):
         idx = ddp.shard_indices(B * world, rank, world, start=i * B * world)
@@ -152,9 +184,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    progress("warm-up: %d steps" % args.warmup)
     for i in range(args.warmup):
         one_step(i)
     fence()
+    progress("timing %d steps" % args.steps)
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))
     t0 = time.perf_counter()
@@ -171,6 +205,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    progress("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     result = None
     if rank == 0:
         nn_avg_s = float(nn_ms.mean()) * 1e-3 if len(nn_ms) else float("nan")
@@ -205,6 +240,7 @@ def main():
                                   "flop_per_eval": 6}},
         }
         if world == 1 and not args.no_parity:
+            progress("pose parity vs the CPU restatement")
             result["pose_parity_vs_cpu_restatement"] = pose_parity(model, params, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(params)

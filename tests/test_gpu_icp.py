@@ -115,7 +115,8 @@ def test_icp_forward_matches_oracle(icp_type, loss, dim):
     saved = T.grad_fn.saved_tensors
     idx_hist, T_hist = saved[3].cpu().numpy(), saved[4].cpu().numpy().reshape(K + 1, B, 4, 4)
     for k in range(out["num_iter"]):
-        np.testing.assert_array_equal(idx_hist[k], out["hist"]["idx"][k].numpy(), err_msg="iteration %d" % k)
+        act = out["hist"]["active"][k].numpy()
+        np.testing.assert_array_equal(idx_hist[k][act], out["hist"]["idx"][k].numpy()[act], err_msg="iteration %d" % k)
         np.testing.assert_allclose(T_hist[k + 1], out["hist"]["T"][k + 1].numpy(), atol=2e-6)
     Tg = T.detach().cpu().numpy()
     np.testing.assert_allclose(Tg, out["T"].numpy(), atol=2e-6)
@@ -254,7 +255,8 @@ def test_config5_50k_fp32_gate():
     T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=torch.from_numpy(T0).to(DEV), weight=wt, **kw)["T"]
     idx_hist = T.grad_fn.saved_tensors[3].cpu().numpy()
     for k in range(out["num_iter"]):
-        np.testing.assert_array_equal(idx_hist[k], out["hist"]["idx"][k].numpy())
+        act = out["hist"]["active"][k].numpy()          # frozen pairs skip the NN kernel
+        np.testing.assert_array_equal(idx_hist[k][act], out["hist"]["idx"][k].numpy()[act])
     Tg, Tr = T.detach().cpu().numpy(), out["T"].numpy()
     assert np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max() <= 1e-3
     assert np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max() <= 1e-4
