@@ -160,6 +160,40 @@ int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, i
 int mmk_bev_raster(const float *pc /*B,M,pc_cols*/, int32_t B, int32_t M, int32_t pc_cols,
                    int32_t W, float cart_resolution, float *bev /*B,W,W*/, void *stream);
 
+/* ------------------------------------------------------------------ mask U-Net building blocks
+ * Replace nn.Conv2d(3x3, pad 1) + ReLU [+ Dropout] and their autograd of the reference's
+ * mask predictor (mm_masking/icp_weight_policy.py:84-99 topology, :104-125 conv_block,
+ * :161-184 forward) for its default configuration (ReLU, no batch norm).  Activations are
+ * NHWC bf16 (B,H,W,C), C in {8,16,32,64,128,256}; accumulation fp32 on the matrix cores.   */
+typedef struct {
+    const void *x1;        /* bf16 (B,H,W,C1)                                              */
+    const void *x2;        /* bf16 (B,H,W,C2) or NULL: the input is concat(x1, x2) — the
+                              torch.cat([skip, x]) of icp_weight_policy.py:180 without a copy */
+    int32_t C1, C2;
+    const void *wpack;     /* from mmk_conv3x3_pack_weights                                */
+    const float *bias;     /* [O1+O2] fp32 or NULL                                          */
+    void *y1;              /* bf16 (B,H,W,O1): output channels [0,O1)                       */
+    const void *relu_src1; /* optional bf16 (B,H,W,O1): y1 = result * (relu_src1 > 0 ? scale1 : 0)
+                              (ReLU / dropout backward fused into the data-gradient pass)   */
+    int32_t O1, accumulate1; /* accumulate: y1 += result                                    */
+    float scale1;
+    void *y2;              /* bf16 (B,H,W,O2) or NULL: output channels [O1,O1+O2)           */
+    const void *relu_src2;
+    int32_t O2, accumulate2;
+    float scale2;
+    int32_t B, H, W;
+    int32_t relu;          /* forward: ReLU after the bias                                  */
+    float drop_p;          /* forward: inverted dropout with this probability (0 = none)    */
+    uint32_t seed;
+} mmk_conv_desc;
+
+/* Packed bf16 element count / packing of fp32 master weights W[cout][cin][3][3].
+ * transposed = 1 packs the data-gradient operator (cout -> cin, taps flipped).            */
+size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t transposed);
+int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t cin, int32_t transposed,
+                             void *packed, void *stream);
+int mmk_conv3x3(const mmk_conv_desc *d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

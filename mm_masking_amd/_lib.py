@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "libmmk_hip.so")
-SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip"]
+SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip"]
 
 _lib = None
 
@@ -37,6 +37,18 @@ class IcpParams(ctypes.Structure):
                 ("loss", ctypes.c_int32), ("loss_k", ctypes.c_float), ("trim_dist", ctypes.c_float),
                 ("tolerance", ctypes.c_float), ("max_iter", ctypes.c_int32), ("save_state", ctypes.c_int32),
                 ("check_every", ctypes.c_int32)]
+
+
+class ConvDesc(ctypes.Structure):
+    """mmk_conv_desc of include/mmk.h."""
+    _fields_ = [("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32),
+                ("wpack", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("y1", ctypes.c_void_p), ("relu_src1", ctypes.c_void_p), ("O1", ctypes.c_int32),
+                ("accumulate1", ctypes.c_int32), ("scale1", ctypes.c_float),
+                ("y2", ctypes.c_void_p), ("relu_src2", ctypes.c_void_p), ("O2", ctypes.c_int32),
+                ("accumulate2", ctypes.c_int32), ("scale2", ctypes.c_float),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32),
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32)]
 
 
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
@@ -75,6 +87,9 @@ def _declare(lib):
         "mmk_nn_search": (ctypes.c_int, [c_vp, c_vp, c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp, sz, c_vp]),
         "mmk_nn_profile_begin": (ctypes.c_int, [i32]),
         "mmk_nn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(ctypes.c_int32)]),
+        "mmk_conv3x3_packed_elems": (sz, [i32, i32, i32]),
+        "mmk_conv3x3_pack_weights": (ctypes.c_int, [c_vp, i32, i32, i32, c_vp, c_vp]),
+        "mmk_conv3x3": (ctypes.c_int, [ctypes.POINTER(ConvDesc), c_vp]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
         "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,

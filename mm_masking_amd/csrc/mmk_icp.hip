@@ -9,6 +9,8 @@
 // operations are written in the same order as there and this file MUST be built
 // with -ffp-contract=off so that only the explicit fmaf calls fuse.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -18,8 +20,6 @@ namespace {
 
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 1024;  // target points staged in LDS per tile
-constexpr int NN_CHUNK = 8;    // targets per running-minimum chunk
-constexpr int NN_P = 2;        // source points held in registers per lane
 constexpr float NN_PAD = 3.0e18f;
 constexpr int ACC_THREADS = 256;
 
@@ -71,155 +71,143 @@ __global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int col
 }
 
 // ------------------------------------------------------------------------------------------
-// I2: brute-force NN.  One lane owns NN_P transformed source points in VGPRs; the target
+// I2: brute-force NN.  One lane owns P transformed source points in VGPRs; the target
 // streams through LDS in planar tiles (wave-uniform ds_read_b128 broadcasts).  Per chunk
-// of 8 targets only the chunk minimum is tracked (v_min3) together with the id of the
+// of CHUNK targets only the chunk minimum is tracked (v_min3) together with the id of the
 // first chunk that attained it; the winning chunk is re-scanned at the end with a strict
 // '<' in ascending order, which yields exactly the lowest-index argmin of the oracle.
-// Grid: 1-D, XCD-aware: blocks of one pair share an XCD (b % 8 label) so its target
-// planes stay in that XCD's L2.
-template <int DIM>
+// Work is cut into units (pair, source block, target range); a persistent 1-D grid walks
+// them with stride gridDim.x.  Units are numbered so that unit % 8 == pair % 8: blocks of
+// one pair share an XCD (blockIdx % 8 label) and its target planes stay in that L2.
+// The partial results of the target ranges meet in one 64-bit atomic min per source point
+// on the key (float bits of d2) << 32 | index: d2 >= 0, so unsigned order == float order,
+// and equal distances resolve to the lowest index; min is order independent, so the
+// result is deterministic.
+template <int DIM, int CHUNK, int P>
 __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
     const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ Tk,
-    const int32_t *__restrict__ active, int B, int N, int Mpad, int nsb, int S, int tiles_per_split,
-    float *__restrict__ pd, int32_t *__restrict__ pi)
+    const int32_t *__restrict__ active, int B, int N, int Mpad, int nsb, int ntu, int tiles_per_unit,
+    int total_units, unsigned long long *__restrict__ packed)
 {
     __shared__ __attribute__((aligned(16))) float lt[DIM][NN_TILE];
-
-    const int g = blockIdx.x;
-    const int xcd = g & 7;
-    const int slot = g >> 3;
-    const int nb = nsb * S;
-    const int b = (slot / nb) * 8 + xcd;
-    if (b >= B) return;
-    if (active != nullptr && active[b] == 0) return;
-    const int within = slot % nb;
-    const int sb = within / S;
-    const int split = within % S;
     const int tid = threadIdx.x;
-
-    float T[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
-
-    float p[NN_P][DIM];
-    float best[NN_P];
-    int bch[NN_P];
-    int pidx[NN_P];
-#pragma unroll
-    for (int q = 0; q < NN_P; ++q) {
-        int i = sb * (NN_THREADS * NN_P) + q * NN_THREADS + tid;
-        pidx[q] = i;
-        float s[3] = {0.f, 0.f, 0.f};
-        if (i < N) {
-            const float *sp = src + ((size_t)b * N + i) * 3;
-            s[0] = sp[0];
-            s[1] = sp[1];
-            s[2] = sp[2];
-        }
-        transform_point<DIM>(T, s, p[q]);
-        best[q] = INFINITY;
-        bch[q] = 0;
-    }
-
     const int ntiles = Mpad / NN_TILE;
-    const int t0 = split * tiles_per_split;
-    const int t1 = min(ntiles, t0 + tiles_per_split);
-    const float *tb = tgtp + (size_t)b * DIM * Mpad;
 
-    for (int t = t0; t < t1; ++t) {
-        __syncthreads();
+    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+        const int xcd = u & 7;
+        int rest = u >> 3;
+        const int tu = rest % ntu;
+        rest /= ntu;
+        const int sb = rest % nsb;
+        const int b = (rest / nsb) * 8 + xcd;
+        if (b >= B) continue;
+        if (active != nullptr && active[b] == 0) continue;
+
+        float T[16];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            // NN_TILE floats per plane = 256 lanes x float4
-            const float4 v = *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
-            *reinterpret_cast<float4 *>(&lt[c][tid * 4]) = v;
+        for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
+
+        float p[P][DIM];
+        float best[P];
+        int bch[P];
+        int pidx[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int i = sb * (NN_THREADS * P) + q * NN_THREADS + tid;
+            pidx[q] = i;
+            float s[3] = {0.f, 0.f, 0.f};
+            if (i < N) {
+                const float *sp = src + ((size_t)b * N + i) * 3;
+                s[0] = sp[0];
+                s[1] = sp[1];
+                s[2] = sp[2];
+            }
+            transform_point<DIM>(T, s, p[q]);
+            best[q] = INFINITY;
+            bch[q] = 0;
         }
-        __syncthreads();
-        const int chunk0 = t * (NN_TILE / NN_CHUNK);
-#pragma unroll 2
-        for (int c = 0; c < NN_TILE / NN_CHUNK; ++c) {
-            float tx[NN_CHUNK], ty[NN_CHUNK], tz[NN_CHUNK];
+
+        const int t0 = tu * tiles_per_unit;
+        const int t1 = min(ntiles, t0 + tiles_per_unit);
+        const float *tb = tgtp + (size_t)b * DIM * Mpad;
+
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();
 #pragma unroll
-            for (int h = 0; h < NN_CHUNK / 4; ++h) {
-                float4 vx = *reinterpret_cast<const float4 *>(&lt[0][c * NN_CHUNK + h * 4]);
-                float4 vy = *reinterpret_cast<const float4 *>(&lt[1][c * NN_CHUNK + h * 4]);
-                tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
-                ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
-                if (DIM == 3) {
-                    float4 vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][c * NN_CHUNK + h * 4]);
-                    tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
-                } else {
-                    tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
+            for (int c = 0; c < DIM; ++c) {
+                // NN_TILE floats per plane = 256 lanes x float4
+                const float4 v =
+                    *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
+                *reinterpret_cast<float4 *>(&lt[c][tid * 4]) = v;
+            }
+            __syncthreads();
+            const int chunk0 = t * (NN_TILE / CHUNK);
+#pragma unroll 2
+            for (int c = 0; c < NN_TILE / CHUNK; ++c) {
+                float tx[CHUNK], ty[CHUNK], tz[CHUNK];
+#pragma unroll
+                for (int h = 0; h < CHUNK / 4; ++h) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][c * CHUNK + h * 4]);
+                    const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][c * CHUNK + h * 4]);
+                    tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
+                    ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
+                    if (DIM == 3) {
+                        const float4 vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][c * CHUNK + h * 4]);
+                        tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
+                    } else {
+                        tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    float m = nn_dist<DIM>(tx[0], ty[0], tz[0], p[q]);
+#pragma unroll
+                    for (int j = 1; j + 1 < CHUNK; j += 2)
+                        m = __builtin_fminf(__builtin_fminf(m, nn_dist<DIM>(tx[j], ty[j], tz[j], p[q])),
+                                            nn_dist<DIM>(tx[j + 1], ty[j + 1], tz[j + 1], p[q]));
+                    m = __builtin_fminf(m, nn_dist<DIM>(tx[CHUNK - 1], ty[CHUNK - 1], tz[CHUNK - 1], p[q]));
+                    const bool better = m < best[q];
+                    best[q] = better ? m : best[q];
+                    bch[q] = better ? (chunk0 + c) : bch[q];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < NN_P; ++q) {
-                float d[NN_CHUNK];
-#pragma unroll
-                for (int j = 0; j < NN_CHUNK; ++j) d[j] = nn_dist<DIM>(tx[j], ty[j], tz[j], p[q]);
-                float m = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
-                m = __builtin_fminf(__builtin_fminf(m, d[3]), d[4]);
-                m = __builtin_fminf(__builtin_fminf(m, d[5]), d[6]);
-                m = __builtin_fminf(m, d[7]);
-                const bool better = m < best[q];
-                best[q] = better ? m : best[q];
-                bch[q] = better ? (chunk0 + c) : bch[q];
-            }
         }
-    }
 
 #pragma unroll
-    for (int q = 0; q < NN_P; ++q) {
-        const int i = pidx[q];
-        if (i >= N) continue;
-        const int j0 = bch[q] * NN_CHUNK;
-        float cur = INFINITY;
-        int jj = j0;
+        for (int q = 0; q < P; ++q) {
+            const int i = pidx[q];
+            if (i >= N) continue;
+            const int j0 = bch[q] * CHUNK;
+            float cur = INFINITY;
+            int jj = j0;
 #pragma unroll
-        for (int j = 0; j < NN_CHUNK; ++j) {
-            float tx = tb[j0 + j];
-            float ty = tb[(size_t)Mpad + j0 + j];
-            float tz = (DIM == 3) ? tb[(size_t)2 * Mpad + j0 + j] : 0.f;
-            float d = nn_dist<DIM>(tx, ty, tz, p[q]);
-            if (d < cur) {
-                cur = d;
-                jj = j0 + j;
+            for (int j = 0; j < CHUNK; ++j) {
+                const float tx = tb[j0 + j];
+                const float ty = tb[(size_t)Mpad + j0 + j];
+                const float tz = (DIM == 3) ? tb[(size_t)2 * Mpad + j0 + j] : 0.f;
+                const float d = nn_dist<DIM>(tx, ty, tz, p[q]);
+                if (d < cur) {
+                    cur = d;
+                    jj = j0 + j;
+                }
             }
-        }
-        const size_t o = ((size_t)b * S + split) * N + i;
-        pd[o] = cur;
-        pi[o] = jj;
-    }
-}
-
-// Merge the per-split partial results (ascending split order, strict '<').
-__device__ __forceinline__ void nn_merge(const float *__restrict__ pd, const int32_t *__restrict__ pi, int b,
-                                         int i, int N, int S, float &best, int &bi)
-{
-    best = INFINITY;
-    bi = 0;
-    for (int s = 0; s < S; ++s) {
-        const size_t o = ((size_t)b * S + s) * N + i;
-        const float d = pd[o];
-        if (d < best) {
-            best = d;
-            bi = pi[o];
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(cur) << 32) | (unsigned long long)(unsigned)jj;
+            atomicMin(&packed[(size_t)b * N + i], key);
         }
     }
 }
 
-__global__ void nn_merge_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi, int N, int S,
-                                int32_t *__restrict__ idx, float *__restrict__ d2)
+constexpr unsigned long long NN_KEY_INIT = ~0ull;
+
+__global__ void nn_unpack_kernel(const unsigned long long *__restrict__ packed, int n, int32_t *__restrict__ idx,
+                                 float *__restrict__ d2)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int b = blockIdx.y;
-    if (i >= N) return;
-    float best;
-    int bi;
-    nn_merge(pd, pi, b, i, N, S, best, bi);
-    idx[(size_t)b * N + i] = bi;
-    d2[(size_t)b * N + i] = best;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = packed[i];
+    idx[i] = (int32_t)(unsigned)(key & 0xffffffffull);
+    d2[i] = __uint_as_float((unsigned)(key >> 32));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,8 +300,8 @@ template <int DIM, int TYPE>
 __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
     const float *__restrict__ src, const float *__restrict__ tgt, int tgt_cols,
     const float *__restrict__ weight, const float *__restrict__ Tk, const int32_t *__restrict__ active,
-    const float *__restrict__ pd, const int32_t *__restrict__ pi, int S, int32_t *__restrict__ idx_out, int N,
-    int M, int loss, float k, float k2, float trim2, double *__restrict__ partials)
+    unsigned long long *__restrict__ packed, int32_t *__restrict__ idx_out, int N, int M, int loss, float k,
+    float k2, float trim2, double *__restrict__ partials)
 {
     constexpr int P = PointTerms<DIM, TYPE>::P;
     constexpr int NR = PointTerms<DIM, TYPE>::NR;
@@ -329,9 +317,10 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
         float T[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) T[q] = Tk[(size_t)b * 16 + q];
-        float bestd;
-        int j;
-        nn_merge(pd, pi, b, i, N, S, bestd, j);
+        // consume the NN key and re-arm it for the next iteration's atomic min
+        const unsigned long long key = packed[(size_t)b * N + i];
+        packed[(size_t)b * N + i] = NN_KEY_INIT;
+        const int j = (int)(unsigned)(key & 0xffffffffull);
         idx_out[(size_t)b * N + i] = j;
         const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
         PointTerms<DIM, TYPE> t;
@@ -792,23 +781,41 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
-    int Mpad, ntiles, nsb, S, tiles_per_split, grid;
+    int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P;
+};
+
+// Tuning knobs of the NN kernel; MMK_NN_VARIANT = "<chunk>,<P>,<tiles_per_unit>" overrides
+// them for experiments (scripts/bench_nn.py).
+struct NNTune {
+    int chunk = 16, P = 2, tiles_per_unit = 2;
+    NNTune()
+    {
+        if (const char *e = getenv("MMK_NN_VARIANT")) {
+            int c = 0, p = 0, t = 0;
+            if (sscanf(e, "%d,%d,%d", &c, &p, &t) == 3 && (c == 8 || c == 16) && (p == 1 || p == 2 || p == 4) && t >= 1) {
+                chunk = c;
+                P = p;
+                tiles_per_unit = t;
+            }
+        }
+    }
 };
 
 NNPlan nn_plan(int B, int N, int M)
 {
+    static const NNTune tune;
     NNPlan pl;
+    pl.chunk = tune.chunk;
+    pl.P = tune.P;
     pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
     pl.ntiles = pl.Mpad / NN_TILE;
-    pl.nsb = (N + NN_THREADS * NN_P - 1) / (NN_THREADS * NN_P);
-    // enough waves to give every SIMD of the 256 CUs several to choose from
-    const int want_blocks = 1536;
-    int S = (want_blocks + B * pl.nsb - 1) / (B * pl.nsb);
-    S = std::max(1, std::min(S, std::min(pl.ntiles, 16)));
-    pl.tiles_per_split = (pl.ntiles + S - 1) / S;
-    pl.S = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
+    pl.tiles_per_unit = std::min(tune.tiles_per_unit, pl.ntiles);
+    pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
-    pl.grid = Bpad * pl.nsb * pl.S;
+    pl.total_units = Bpad * pl.nsb * pl.ntu;
+    // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs)
+    pl.grid = std::min(pl.total_units, 2048);
     return pl;
 }
 
@@ -821,17 +828,27 @@ struct NNProf {
 };
 NNProf g_prof;
 
+template <int DIM, int CHUNK, int P>
+void launch_nn_t(const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
+                 const NNPlan &pl, unsigned long long *packed, hipStream_t st)
+{
+    hipLaunchKernelGGL((nn_search_kernel<DIM, CHUNK, P>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active,
+                       B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, packed);
+}
+
+// `packed` (B,N) must hold NN_KEY_INIT on entry (memset 0xFF or re-armed by the accumulate kernel).
 int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
-              const NNPlan &pl, float *pd, int32_t *pi, hipStream_t st)
+              const NNPlan &pl, unsigned long long *packed, hipStream_t st)
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
-    if (dim == 2)
-        hipLaunchKernelGGL(nn_search_kernel<2>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
-                           pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
-    else
-        hipLaunchKernelGGL(nn_search_kernel<3>, dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, B, N,
-                           pl.Mpad, pl.nsb, pl.S, pl.tiles_per_split, pd, pi);
+#define MMK_NN_CASE(D, C, PP) \
+    if (dim == D && pl.chunk == C && pl.P == PP) launch_nn_t<D, C, PP>(src, tgtp, Tk, active, B, N, pl, packed, st)
+    MMK_NN_CASE(2, 8, 1); MMK_NN_CASE(2, 8, 2); MMK_NN_CASE(2, 8, 4);
+    MMK_NN_CASE(2, 16, 1); MMK_NN_CASE(2, 16, 2); MMK_NN_CASE(2, 16, 4);
+    MMK_NN_CASE(3, 8, 1); MMK_NN_CASE(3, 8, 2); MMK_NN_CASE(3, 8, 4);
+    MMK_NN_CASE(3, 16, 1); MMK_NN_CASE(3, 16, 2); MMK_NN_CASE(3, 16, 4);
+#undef MMK_NN_CASE
     MMK_LAUNCH_CHECK();
     if (rec) {
         MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
@@ -856,8 +873,7 @@ int check_params(const mmk_icp_params *p)
 
 struct IcpWs {
     float *tgtp;
-    float *pd;
-    int32_t *pi;
+    unsigned long long *packed;  // (B,N) NN keys
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
     double *lam;        // backward (B,6)
@@ -872,8 +888,7 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     mmk::Arena ar(ws, cap);
     IcpWs w;
     w.tgtp = ar.take<float>((size_t)p->B * p->dim * pl.Mpad);
-    w.pd = ar.take<float>((size_t)p->B * pl.S * p->N);
-    w.pi = ar.take<int32_t>((size_t)p->B * pl.S * p->N);
+    w.packed = ar.take<unsigned long long>((size_t)p->B * p->N);
     w.partials = ar.take<double>((size_t)p->B * nblk * 27);
     w.G0 = ar.take<double>((size_t)p->B * 16);
     w.G1 = ar.take<double>((size_t)p->B * 16);
@@ -893,15 +908,15 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
+    MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
     for (int it = 0; it < p->max_iter; ++it) {
         const float *Tk = T_hist + (size_t)it * B * 16;
         const int32_t *act = active_hist + (size_t)it * B;
         int32_t *idx = idx_hist + (p->save_state ? (size_t)it * B * N : 0);
-        int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.pd, w.pi, st);
+        int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.packed, st);
         if (rc != MMK_OK) return rc;
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
-                           p->tgt_cols, weight, Tk, act, w.pd, w.pi, pl.S, idx, N, M, p->loss, k, k2, trim2,
-                           w.partials);
+                           p->tgt_cols, weight, Tk, act, w.packed, idx, N, M, p->loss, k, k2, trim2, w.partials);
         MMK_LAUNCH_CHECK();
         hipLaunchKernelGGL(icp_solve_kernel<DIM>, dim3(B), dim3(64), 0, st, w.partials, nblk, Tk,
                            T_hist + (size_t)(it + 1) * B * 16, delta_hist + (size_t)it * B * 6,
@@ -986,8 +1001,7 @@ extern "C" size_t mmk_nn_workspace_bytes(int32_t B, int32_t N, int32_t M, int32_
 {
     (void)dim;
     if (B < 1 || N < 1 || M < 1) return 0;
-    const NNPlan pl = nn_plan(B, N, M);
-    return mmk::align_up((size_t)B * pl.S * N * 4, 256) * 2 + 512;
+    return mmk::align_up((size_t)B * N * sizeof(unsigned long long), 256) + 256;
 }
 
 extern "C" int mmk_nn_search(const float *source, const float *target_planar, const float *T, int32_t B, int32_t N,
@@ -999,16 +1013,16 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     MMK_REQUIRE(dim == 2 || dim == 3, "mmk_nn_search: dim must be 2 or 3");
     const NNPlan pl = nn_plan(B, N, M);
     mmk::Arena ar(workspace, workspace_bytes);
-    float *pd = ar.take<float>((size_t)B * pl.S * N);
-    int32_t *pi = ar.take<int32_t>((size_t)B * pl.S * N);
+    unsigned long long *packed = ar.take<unsigned long long>((size_t)B * N);
     if (!ar.ok() || workspace == nullptr) {
         mmk::set_error("mmk_nn_search: workspace too small (%zu < %zu)", workspace_bytes, ar.off);
         return MMK_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_nn(dim, source, target_planar, T, nullptr, B, N, pl, pd, pi, st);
+    MMK_CHECK_HIP(hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
+    int rc = launch_nn(dim, source, target_planar, T, nullptr, B, N, pl, packed, st);
     if (rc != MMK_OK) return rc;
-    hipLaunchKernelGGL(nn_merge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, pd, pi, N, pl.S, idx, d2);
+    hipLaunchKernelGGL(nn_unpack_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, packed, B * N, idx, d2);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -1,0 +1,308 @@
+// Mask U-Net building blocks on gfx950: NHWC bf16 activations, fp32 accumulation on the
+// matrix cores (v_mfma_f32_16x16x32_bf16), fused bias / ReLU / dropout / ReLU-backward
+// epilogues.  Replaces the nn.Conv2d / MaxPool2d / UpsamplingBilinear2d / Sigmoid stack of
+// the reference's mask predictor (mm_masking/icp_weight_policy.py:84-99,104-125,161-184)
+// for its default configuration (ReLU, no batch norm).
+//
+// 3x3 convolution as an implicit GEMM, weights as the MFMA A operand (rows = output
+// channels) and pixels as the B operand (columns = 16 consecutive pixels of one image
+// row), so that every lane ends up with 4 consecutive output channels of one pixel
+// (8-byte NHWC stores) and every B fragment is one 16-byte LDS read of 8 consecutive
+// input channels of one pixel at one tap.  The same kernel computes the data gradient
+// (weights packed transposed + flipped).  The weight gradient contracts over pixels:
+// both operands are read from row-major [pixel][channel] LDS tiles with the transposing
+// ds_read_b64_tr_b16.
+#include <math.h>
+
+#include "mmk_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TH = 8, TW = 32;            // output pixels per block tile
+constexpr int HT = TH + 2, WT = TW + 2;   // halo tile
+constexpr int CONV_THREADS = 256;
+
+__host__ __device__ constexpr int ksteps(int ck) { return ck >= 32 ? 9 * (ck / 32) : (ck == 16 ? 5 : 3); }
+__host__ __device__ constexpr int cin_chunk(int cin) { return cin >= 64 ? 64 : cin; }
+__host__ __device__ constexpr int cout_group(int cout) { return cout >= 64 ? 64 : (cout <= 16 ? 16 : cout); }
+
+// (tap, channel offset inside the chunk) of the 8 consecutive k values lane `l` holds in k-step `s`.
+template <int CK>
+__device__ __forceinline__ void kslot(int s, int l, int &tap, int &ch)
+{
+    if (CK >= 32) {
+        tap = s / (CK / 32);
+        ch = (s % (CK / 32)) * 32 + 8 * (l >> 4);
+    } else if (CK == 16) {
+        tap = 2 * s + (l >> 5);
+        ch = 8 * ((l >> 4) & 1);
+    } else {
+        tap = 4 * s + (l >> 4);
+        ch = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing: fp32 master weights W[COUT][CIN][3][3] -> bf16 in MFMA A-fragment order
+// [group][chunk][kstep][mtile][lane][8].  transposed = 1 packs the data-gradient operator
+// (out channels = CIN, in channels = COUT, taps flipped).
+__global__ void pack_conv_weights_kernel(const float *__restrict__ W, int COUT, int CIN, int transposed,
+                                         bf16 *__restrict__ out, int total)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int co_n = transposed ? CIN : COUT;   // channels produced by the packed operator
+    const int ci_n = transposed ? COUT : CIN;   // channels consumed
+    const int CK = cin_chunk(ci_n), CM = cout_group(co_n);
+    const int NS = ksteps(CK), MT = CM / 16;
+    const int nchunk = ci_n / CK;
+    int r = e;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int mt = r % MT; r /= MT;
+    const int s = r % NS; r /= NS;
+    const int chunk = r % nchunk;
+    const int group = r / nchunk;
+    int tap, ch;
+    if (CK >= 32) {
+        tap = s / (CK / 32);
+        ch = (s % (CK / 32)) * 32 + 8 * (lane >> 4);
+    } else if (CK == 16) {
+        tap = 2 * s + (lane >> 5);
+        ch = 8 * ((lane >> 4) & 1);
+    } else {
+        tap = 4 * s + (lane >> 4);
+        ch = 0;
+    }
+    const int co = group * CM + mt * 16 + (lane & 15);
+    const int ci = chunk * CK + ch + j;
+    float v = 0.f;
+    if (tap < 9 && co < co_n && ci < ci_n) {
+        if (transposed) v = W[((size_t)ci * CIN + co) * 9 + (8 - tap)];
+        else v = W[((size_t)co * CIN + ci) * 9 + tap];
+    }
+    out[e] = (bf16)v;
+}
+
+struct ConvOutPart {
+    bf16 *y;               // (B,H,W,C)
+    const bf16 *relu_src;  // optional (B,H,W,C): y = acc * (relu_src > 0 ? scale : 0)
+    int C;
+    int accumulate;        // y += result
+    float scale;
+};
+
+struct ConvArgs {
+    const bf16 *x1, *x2;   // input = concat(x1 (C1 channels), x2 (C2 channels)); x2 may be null
+    int C1, C2;
+    const bf16 *wpack;
+    const float *bias;     // [COUT] or null
+    ConvOutPart o1, o2;    // output channels [0,o1.C) -> o1, [o1.C, o1.C+o2.C) -> o2
+    int B, H, W, CIN, COUT;
+    int relu;
+    float drop_p;          // forward dropout on the output (0 = none)
+    unsigned seed;
+};
+
+__device__ __forceinline__ unsigned hash_u32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+// keep-mask scale of inverted dropout for element index e (0 or 1/(1-p))
+__device__ __forceinline__ float dropout_scale(unsigned seed, unsigned e, float p, float inv_keep)
+{
+    const unsigned h = hash_u32(e * 0x9E3779B9U + seed);
+    return ((float)(h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
+template <int CK, int CM>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
+{
+    constexpr int NS = ksteps(CK);
+    constexpr int MT = CM / 16;
+    constexpr int NT = 4;  // per wave: 2 tile rows x 2 halves of 16 pixels
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);                       // HT*WT*CK
+    bf16 *w_lds = in_tile + HT * WT * CK;                                 // NS*MT*64*8
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int group = blockIdx.y, b = blockIdx.z;
+    const int nchunk = a.CIN / CK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (chunk > 0) __syncthreads();
+        // ---- stage the input halo tile (zero padded), 16-byte granules of 8 channels
+        constexpr int GPP = CK / 8;
+        for (int g = tid; g < HT * WT * GPP; g += CONV_THREADS) {
+            const int pix = g / GPP, gc = g % GPP;
+            const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
+            const int c = chunk * CK + gc * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
+                else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
+            }
+            *reinterpret_cast<uint4 *>(in_tile + (size_t)pix * CK + gc * 8) = v;
+        }
+        // ---- stage this (group, chunk) block of packed weights
+        {
+            const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NS * MT * 512);
+            for (int g = tid; g < NS * MT * 64; g += CONV_THREADS) reinterpret_cast<uint4 *>(w_lds)[g] = wsrc[g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            int tap, ch;
+            kslot<CK>(s, lane, tap, ch);
+            tap = tap > 8 ? 8 : tap;  // padded taps carry zero weights
+            const int ty = tap / 3, tx = tap % 3;
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = 2 * wv + (n >> 1), col = (n & 1) * 16 + (lane & 15);
+                bf[n] = *reinterpret_cast<const bf16x8 *>(in_tile + ((size_t)((row + ty) * WT + col + tx)) * CK + ch);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)((s * MT + m) * 64 + lane)) * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels c0..c0+3 of pixel (row, col) for each (m, n)
+    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
+        if (c0 >= a.COUT) continue;
+        const bool first = c0 < a.o1.C;
+        const ConvOutPart &o = first ? a.o1 : a.o2;
+        const int cl = first ? c0 : c0 - a.o1.C;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs[r] = a.bias[c0 + r];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int yy = ty0 + 2 * wv + (n >> 1), xx = tx0 + (n & 1) * 16 + (lane & 15);
+            if (yy >= a.H || xx >= a.W) continue;
+            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[m][n][r] + bs[r];
+                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.drop_p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= dropout_scale(a.seed, (unsigned)(p * a.COUT + c0 + r), a.drop_p, inv_keep);
+            }
+            bf16 *dst = o.y + p * o.C + cl;
+            if (o.relu_src) {
+                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o.relu_src + p * o.C + cl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o.scale : 0.f;
+            }
+            if (o.accumulate) {
+                const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+            }
+            bf16x4 outv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
+            *reinterpret_cast<bf16x4 *>(dst) = outv;
+        }
+    }
+}
+
+template <int CK, int CM>
+int launch_conv(const ConvArgs &a, hipStream_t st)
+{
+    const size_t smem = ((size_t)HT * WT * CK + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
+    if (smem > 64 * 1024)
+        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int groups = (a.COUT + CM - 1) / CM;
+    hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(tiles, groups, a.B), dim3(CONV_THREADS), smem, st, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+int dispatch_conv(const ConvArgs &a, hipStream_t st)
+{
+    const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
+#define MMK_CONV_CASE(K, M) if (CK == K && CM == M) return launch_conv<K, M>(a, st)
+    MMK_CONV_CASE(8, 16); MMK_CONV_CASE(8, 32); MMK_CONV_CASE(8, 64);
+    MMK_CONV_CASE(16, 16); MMK_CONV_CASE(16, 32); MMK_CONV_CASE(16, 64);
+    MMK_CONV_CASE(32, 16); MMK_CONV_CASE(32, 32); MMK_CONV_CASE(32, 64);
+    MMK_CONV_CASE(64, 16); MMK_CONV_CASE(64, 32); MMK_CONV_CASE(64, 64);
+#undef MMK_CONV_CASE
+    mmk::set_error("mmk_conv3x3: unsupported channel counts CIN=%d COUT=%d", a.CIN, a.COUT);
+    return MMK_ERR_ARG;
+}
+
+bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t transposed)
+{
+    const int co_n = transposed ? cin : cout, ci_n = transposed ? cout : cin;
+    if (!chan_ok(co_n) || !chan_ok(ci_n)) return 0;
+    const int CK = cin_chunk(ci_n), CM = cout_group(co_n);
+    const int groups = (co_n + CM - 1) / CM, chunks = ci_n / CK;
+    return (size_t)groups * chunks * ksteps(CK) * (CM / 16) * 512;
+}
+
+extern "C" int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t cin, int32_t transposed, void *packed,
+                                        void *stream)
+{
+    MMK_REQUIRE(W && packed, "mmk_conv3x3_pack_weights: NULL pointer");
+    const size_t total = mmk_conv3x3_packed_elems(cout, cin, transposed);
+    MMK_REQUIRE(total > 0, "mmk_conv3x3_pack_weights: unsupported channel counts %d -> %d", cin, cout);
+    hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       cout, cin, transposed, (bf16 *)packed, (int)total);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
+{
+    MMK_REQUIRE(d != nullptr, "mmk_conv3x3: NULL descriptor");
+    MMK_REQUIRE(d->x1 && d->wpack && d->y1, "mmk_conv3x3: NULL pointer");
+    MMK_REQUIRE(d->B >= 1 && d->H >= 1 && d->W >= 1, "mmk_conv3x3: bad shape");
+    const int cin = d->C1 + d->C2, cout = d->O1 + d->O2;
+    MMK_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0 && (d->C2 == 0 || d->x2), "mmk_conv3x3: bad input split %d+%d", d->C1, d->C2);
+    MMK_REQUIRE(d->O1 % 8 == 0 && d->O2 % 8 == 0 && (d->O2 == 0 || d->y2), "mmk_conv3x3: bad output split %d+%d", d->O1, d->O2);
+    MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3: unsupported channel counts %d -> %d", cin, cout);
+    MMK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "mmk_conv3x3: dropout probability out of range");
+    ConvArgs a;
+    a.x1 = (const bf16 *)d->x1; a.x2 = (const bf16 *)d->x2; a.C1 = d->C1; a.C2 = d->C2;
+    a.wpack = (const bf16 *)d->wpack; a.bias = d->bias;
+    a.o1 = {(bf16 *)d->y1, (const bf16 *)d->relu_src1, d->O1, d->accumulate1, d->scale1};
+    a.o2 = {(bf16 *)d->y2, (const bf16 *)d->relu_src2, d->O2, d->accumulate2, d->scale2};
+    a.B = d->B; a.H = d->H; a.W = d->W; a.CIN = cin; a.COUT = cout;
+    a.relu = d->relu; a.drop_p = d->drop_p; a.seed = d->seed;
+    return dispatch_conv(a, (hipStream_t)stream);
+}
