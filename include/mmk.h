@@ -193,6 +193,14 @@ size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t transposed);
 int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t cin, int32_t transposed,
                              void *packed, void *stream);
 int mmk_conv3x3(const mmk_conv_desc *d, void *stream);
+/* Weight + bias gradient of the same convolution (autograd of nn.Conv2d,
+ * train_icp_weights.py:51): dWt[tap][cout][cin] += sum_pixels g * shifted input, db[cout] += sum g
+ * (fp32, caller zero-initialises; float atomics).  g = gradient w.r.t. the pre-activation.
+ * mmk_conv3x3_wgrad_unpack writes / accumulates it into the parameter's [cout][cin][3][3] layout. */
+int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
+                      int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream);
+int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -261,6 +261,216 @@ int dispatch_conv(const ConvArgs &a, hipStream_t st)
     return MMK_ERR_ARG;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][tap] = sum over pixels of g[p][co] * x[p + tap][ci].
+// GEMM with the contraction over pixels (k = 32 consecutive pixels of one tile row):
+// A = g^T (rows = co), B = shifted x (cols = (tap, ci)); both fragments come out of the
+// row-major [pixel][channel] LDS tiles through ds_read_b64_tr_b16 (4 pixels x 16 channels
+// per 16-lane group, delivered channel-major).  Blocks are persistent over spatial tiles
+// and add their fp32 partial sums once at the end into dWt[tap][co][ci] (64-byte
+// contiguous atomic segments); the bias gradient rides along as an extra all-ones column.
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+__device__ __forceinline__ i32x2 tr_read(unsigned addr)
+{
+    i32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 frag_from(i32x2 lo, i32x2 hi)
+{
+    i32x4 t = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8, t);
+}
+
+struct WgradArgs {
+    const bf16 *x1, *x2;
+    int C1, C2;
+    const bf16 *g;   // (B,H,W,COUT)
+    float *dWt;      // [9][COUT][CIN]
+    float *db;       // [COUT] or null
+    int B, H, W, CIN, COUT;
+};
+
+template <int CK, int CM>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
+{
+    constexpr int MT = CM / 16;
+    constexpr int NTT = (CK >= 16) ? 9 * (CK / 16) : 5;  // n-tiles of 16 (tap, ci) columns
+    constexpr int NTW = (NTT + 3) / 4;                    // per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // HT*WT*CK (+ pad)
+    bf16 *g_tile = x_tile + (HT * WT + 8) * CK;                    // TH*TW*CM (+ pad)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = blockIdx.y, group = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int total_tiles = tiles_x * tiles_y * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+    const int gcols = (a.COUT < CM) ? a.COUT : CM;   // valid columns of the g tile (COUT = 8 -> 8)
+
+    f32x4 acc[MT][NTW];
+    f32x4 accb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+    // per-lane LDS byte offsets that do not depend on the tile
+    unsigned b_off[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nt = wv + 4 * n;
+        int tap, col;
+        if (CK >= 16) {
+            tap = nt / (CK / 16);
+            col = (nt % (CK / 16)) * 16 + 4 * pp;
+        } else {
+            tap = 2 * nt + (pp >> 1);
+            col = 4 * (pp & 1);
+        }
+        tap = tap > 8 ? 8 : tap;
+        const int ty = tap / 3, tx = tap % 3;
+        b_off[n] = (unsigned)((((ty * WT) + 8 * g4 + q + tx) * CK + col) * 2);
+    }
+    const unsigned xbase = lds_addr(x_tile), gbase = lds_addr(g_tile);
+
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y);
+        const int tr = t % (tiles_x * tiles_y);
+        const int tx0 = (tr % tiles_x) * TW, ty0 = (tr / tiles_x) * TH;
+        __syncthreads();
+        constexpr int GPP = CK / 8;
+        for (int gi = tid; gi < HT * WT * GPP; gi += CONV_THREADS) {
+            const int pix = gi / GPP, gc = gi % GPP;
+            const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
+            const int c = chunk * CK + gc * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
+                else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
+            }
+            *reinterpret_cast<uint4 *>(x_tile + (size_t)pix * CK + gc * 8) = v;
+        }
+        const int GPG = gcols / 8;
+        for (int gi = tid; gi < TH * TW * GPG; gi += CONV_THREADS) {
+            const int pix = gi / GPG, gc = gi % GPG;
+            const int yy = ty0 + pix / TW, xx = tx0 + pix % TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy < a.H && xx < a.W)
+                v = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * a.COUT + group * CM + gc * 8);
+            *reinterpret_cast<uint4 *>(g_tile + (size_t)pix * gcols + gc * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < TH; ++r) {
+            i32x2 a_lo[MT], a_hi[MT], b_lo[NTW], b_hi[NTW];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const unsigned ad = gbase + (unsigned)(((r * TW + 8 * g4 + q) * gcols + m * 16 + 4 * pp) * 2);
+                a_lo[m] = tr_read(ad);
+                a_hi[m] = tr_read(ad + (unsigned)(4 * gcols * 2));
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const unsigned ad = xbase + b_off[n] + (unsigned)(r * WT * CK * 2);
+                b_lo[n] = tr_read(ad);
+                b_hi[n] = tr_read(ad + (unsigned)(4 * CK * 2));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 af = frag_from(a_lo[m], a_hi[m]);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    if (wv + 4 * n < NTT)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(b_lo[n], b_hi[n]), acc[m][n], 0, 0, 0);
+                }
+                if (wv == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- one atomic pass per block
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = group * CM + m * 16 + g4 * 4 + rr;
+            if (co >= a.COUT) continue;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int nt = wv + 4 * n;
+                if (nt >= NTT) continue;
+                int tap, ci;
+                if (CK >= 16) {
+                    tap = nt / (CK / 16);
+                    ci = chunk * CK + (nt % (CK / 16)) * 16 + i16;
+                } else {
+                    tap = 2 * nt + (i16 >> 3);
+                    ci = i16 & 7;
+                }
+                if (tap < 9) atomicAdd(&a.dWt[((size_t)tap * a.COUT + co) * a.CIN + ci], acc[m][n][rr]);
+            }
+            if (a.db && wv == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
+        }
+    }
+}
+
+template <int CK, int CM>
+int launch_wgrad(const WgradArgs &a, hipStream_t st)
+{
+    const size_t smem = ((size_t)(HT * WT + 8) * CK + (size_t)(TH * TW + 8) * CM) * sizeof(bf16);
+    if (smem > 64 * 1024)
+        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+    const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
+    int spatial = 768 / (chunks * groups);
+    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CK, CM>), dim3(spatial, chunks, groups), dim3(CONV_THREADS), smem, st, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
+{
+    const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
+#define MMK_WG_CASE(K, M) if (CK == K && CM == M) return launch_wgrad<K, M>(a, st)
+    MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);
+    MMK_WG_CASE(16, 16); MMK_WG_CASE(16, 32); MMK_WG_CASE(16, 64);
+    MMK_WG_CASE(32, 16); MMK_WG_CASE(32, 32); MMK_WG_CASE(32, 64);
+    MMK_WG_CASE(64, 16); MMK_WG_CASE(64, 32); MMK_WG_CASE(64, 64);
+#undef MMK_WG_CASE
+    mmk::set_error("mmk_conv3x3_wgrad: unsupported channel counts CIN=%d COUT=%d", a.CIN, a.COUT);
+    return MMK_ERR_ARG;
+}
+
+// dW[co][ci][tap] (+)= dWt[tap][co][ci]
+__global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int CIN, int accumulate,
+                                    float *__restrict__ dW)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= COUT * CIN * 9) return;
+    const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+    const float v = dWt[((size_t)tap * COUT + co) * CIN + ci];
+    dW[e] = accumulate ? dW[e] + v : v;
+}
+
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
 
 }  // namespace
@@ -305,4 +515,29 @@ extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
     a.B = d->B; a.H = d->H; a.W = d->W; a.CIN = cin; a.COUT = cout;
     a.relu = d->relu; a.drop_p = d->drop_p; a.seed = d->seed;
     return dispatch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
+                                 int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream)
+{
+    MMK_REQUIRE(x1 && g && dWt, "mmk_conv3x3_wgrad: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 1 && W >= 1, "mmk_conv3x3_wgrad: bad shape");
+    const int cin = C1 + C2;
+    MMK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || x2), "mmk_conv3x3_wgrad: bad input split %d+%d", C1, C2);
+    MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3_wgrad: unsupported channel counts %d -> %d", cin, cout);
+    WgradArgs a;
+    a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
+    a.dWt = dWt; a.db = db; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+    return dispatch_wgrad(a, (hipStream_t)stream);
+}
+
+extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
+                                        void *stream)
+{
+    MMK_REQUIRE(dWt && dW && cout >= 1 && cin >= 1, "mmk_conv3x3_wgrad_unpack: bad argument");
+    const int n = cout * cin * 9;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dWt, cout, cin,
+                       accumulate, dW);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
 }

@@ -51,3 +51,25 @@ def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0,
                       seed=int(seed) & 0xFFFFFFFF)
     _lib.check(_lib.lib().mmk_conv3x3(ctypes.byref(d), _lib.stream_ptr(x1.device)))
     return (out, out2) if O2 > 0 else out
+
+
+def conv3x3_wgrad(x1, g, cout, x2=None, dWt=None, db=None):
+    """Accumulate the weight / bias gradient into dWt (9,cout,cin) fp32 and db (cout,) fp32."""
+    B, H, W, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    cin = C1 + C2
+    if dWt is None:
+        dWt = torch.zeros(9, cout, cin, dtype=torch.float32, device=x1.device)
+    _lib.check(_lib.lib().mmk_conv3x3_wgrad(_p(x1), _p(x2), C1, C2, _p(g), cout, B, H, W, _p(dWt), _p(db),
+                                            _lib.stream_ptr(x1.device)))
+    return dWt
+
+
+def wgrad_unpack(dWt, accumulate_into=None):
+    """(9,cout,cin) -> (cout,cin,3,3); accumulates into an existing gradient when given."""
+    _, cout, cin = dWt.shape
+    out = accumulate_into if accumulate_into is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32,
+                                                                          device=dWt.device)
+    _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack(_p(dWt), cout, cin, 1 if accumulate_into is not None else 0, _p(out),
+                                                   _lib.stream_ptr(dWt.device)))
+    return out

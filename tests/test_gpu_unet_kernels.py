@@ -88,3 +88,38 @@ def test_conv3x3_dropout_statistics():
     assert torch.allclose(y[y > 0], torch.tensor(1.0 / 0.75, device=DEV), atol=0.01)
     y2 = uh.conv3x3(x, wp, 8, relu=True, drop_p=0.25, seed=124).float()
     assert (y2 != y).any() and torch.equal(uh.conv3x3(x, wp, 8, relu=True, drop_p=0.25, seed=123).float(), y)
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(8, 8, 16, 32), (8, 16, 24, 40), (16, 16, 40, 64), (16, 8, 17, 33),
+                                           (16, 32, 20, 20), (32, 32, 16, 64), (32, 16, 9, 31), (32, 64, 16, 32),
+                                           (64, 64, 20, 20), (64, 32, 8, 32), (64, 128, 10, 10), (128, 128, 12, 20),
+                                           (128, 64, 8, 8), (128, 256, 6, 10), (256, 256, 5, 7), (256, 128, 20, 20)])
+def test_conv3x3_wgrad(cin, cout, H, W):
+    B = 3
+    x = _rand_nhwc(B, H, W, cin, 100 + cin)
+    gy = _rand_nhwc(B, H, W, cout, 200 + cout)
+    w = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    bias = torch.zeros(cout, device=DEV, requires_grad=True)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=1)
+    y.backward(gy.float().permute(0, 3, 1, 2))
+    db = torch.zeros(cout, device=DEV)
+    dWt = uh.conv3x3_wgrad(x, gy, cout, db=db)
+    dW = uh.wgrad_unpack(dWt)
+    scale = w.grad.abs().max().item()
+    assert (dW - w.grad).abs().max().item() < 2e-3 * scale + 1e-3, ((dW - w.grad).abs().max().item(), scale)
+    assert (db - bias.grad).abs().max().item() < 2e-3 * bias.grad.abs().max().item() + 1e-3
+    # accumulation of a second application (shared decoder weights) and into an existing .grad
+    dWt2 = uh.conv3x3_wgrad(x, gy, cout, dWt=dWt.clone())
+    acc = uh.wgrad_unpack(dWt2, accumulate_into=torch.ones_like(dW))
+    assert (acc - (2 * w.grad + 1)).abs().max().item() < 4e-3 * scale + 2e-3
+
+
+def test_conv3x3_wgrad_concat():
+    B, H, W = 2, 24, 40
+    xa, xb = _rand_nhwc(B, H, W, 8, 1), _rand_nhwc(B, H, W, 8, 2)
+    gy = _rand_nhwc(B, H, W, 8, 3)
+    w = torch.zeros(8, 16, 3, 3, device=DEV, requires_grad=True)
+    y = F.conv2d(torch.cat([xa, xb], 3).float().permute(0, 3, 1, 2), w, padding=1)
+    y.backward(gy.float().permute(0, 3, 1, 2))
+    dW = uh.wgrad_unpack(uh.conv3x3_wgrad(xa, gy, 8, x2=xb))
+    assert (dW - w.grad).abs().max().item() < 2e-3 * w.grad.abs().max().item() + 1e-3
