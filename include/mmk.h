@@ -202,6 +202,35 @@ int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, co
 int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
                              void *stream);
 
+/* First conv of the network (encoder.0.0): fp32 NCHW input (B,cin,H,W), cin = 1..4
+ * (fft | cfar | range channels, icp_weight_policy.py:84), W[8][cin][3][3], + bias + ReLU ->
+ * bf16 (B,H,W,8).  _wgrad: dW[8][cin][3][3] += , db[8] += (g = grad w.r.t. the pre-activation). */
+int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, int32_t B, int32_t H,
+                   int32_t Wd, void *y, void *stream);
+int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, int32_t B, int32_t H, int32_t Wd,
+                         float *dW, float *db, void *stream);
+
+/* nn.MaxPool2d(2,2) on NHWC bf16 (icp_weight_policy.py:122-123).  _bwd fuses the backward of
+ * the preceding Dropout(ReLU(.)): gz = route(gy) * (d > 0 ? scale : 0), d = the pooled tensor's
+ * source (B,H,W,C).                                                                          */
+int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *stream);
+int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
+                     void *gz, void *stream);
+
+/* nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (icp_weight_policy.py:175-176).
+ * _bwd is the adjoint in gather form; relu_src (optional, source-sized) applies
+ * (relu_src > 0 ? scale : 0).                                                                */
+int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo, void *y,
+                     void *stream);
+int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo,
+                     const void *relu_src, float scale, void *gx, void *stream);
+
+/* final_layer: Conv2d(8,1,1x1) + Sigmoid (icp_weight_policy.py:96-99,184): bf16 (npix,8) -> fp32
+ * mask (npix).  _bwd: gx = dL/dx * (x > 0 ? scale : 0) (bf16), dW[8] +=, db[1] +=.            */
+int mmk_final_fwd(const void *x, const float *w, const float *bias, int64_t npix, float *mask, void *stream);
+int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
+                  void *gx, float *dW, float *db, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

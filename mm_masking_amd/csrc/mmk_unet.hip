@@ -14,6 +14,8 @@
 // ds_read_b64_tr_b16.
 #include <math.h>
 
+#include <algorithm>
+
 #include "mmk_common.h"
 
 namespace {
@@ -471,6 +473,293 @@ __global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int
     dW[e] = accumulate ? dW[e] + v : v;
 }
 
+// ------------------------------------------------------------------------------------------
+// First layer: fp32 NCHW input with 1..4 channels -> 8 channels NHWC bf16 (+bias, ReLU).
+// 72..288 FMAs per pixel: plain VALU, HBM-bound.
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
+                                                         const float *__restrict__ bias, int B, int H, int W,
+                                                         bf16 *__restrict__ y)
+{
+    __shared__ float ws[8 * 4 * 9 + 8];
+    for (int i = threadIdx.x; i < 8 * CIN * 9; i += blockDim.x) ws[i] = Wt[i];
+    if (threadIdx.x < 8) ws[8 * 4 * 9 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        float acc[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = ws[8 * 4 * 9 + co];
+        for (int c = 0; c < CIN; ++c) {
+            const float *xc = x + ((size_t)b * CIN + c) * H * W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+                float v = 0.f;
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = xc[(size_t)y2 * W + x2];
+                // bf16 operands as on the MFMA path
+                v = (float)(bf16)v;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc[co] += v * ws[(co * CIN + c) * 9 + tap];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) o[co] = (bf16)fmaxf(acc[co], 0.f);
+        *reinterpret_cast<bf16x8 *>(y + p * 8) = o;
+    }
+}
+
+// dW[8][CIN][9] += sum_p g[p][co] * x[c][p+tap], db[8] += sum_p g[p][co]  (g = grad w.r.t. pre-activation)
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
+                                                               int B, int H, int W, float *__restrict__ dW,
+                                                               float *__restrict__ db)
+{
+    __shared__ float red[4][80];
+    const size_t npix = (size_t)B * H * W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = 0; c < CIN; ++c) {
+        float acc[80];
+#pragma unroll
+        for (int i = 0; i < 80; ++i) acc[i] = 0.f;
+        for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+            const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+            const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(g + p * 8);
+            const float *xc = x + ((size_t)b * CIN + c) * H * W;
+            float xv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+                float v = 0.f;
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = xc[(size_t)y2 * W + x2];
+                xv[tap] = (float)(bf16)v;
+            }
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                const float gf = (float)gv[co];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[co * 9 + tap] += gf * xv[tap];
+                acc[72 + co] += gf;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 80; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wv][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 80) {
+            const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            const int i = threadIdx.x;
+            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], v);
+            else if (c == 0 && db) atomicAdd(&db[i - 72], v);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2x2 / stride 2 max pooling (nn.MaxPool2d(2,2), icp_weight_policy.py:122-123), NHWC bf16,
+// one thread per (output pixel, 8-channel granule).
+__global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, int W, int C, bf16 *__restrict__ y)
+{
+    const int Ho = H / 2, Wo = W / 2, G = C / 8;
+    const size_t n = (size_t)B * Ho * Wo * G;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int gc = (int)(e % G);
+    const size_t po = e / G;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), b = (int)(po / ((size_t)Wo * Ho));
+    const bf16 *src = x + ((((size_t)b * H + 2 * yo) * W + 2 * xo) * C + gc * 8);
+    const bf16x8 v00 = *reinterpret_cast<const bf16x8 *>(src);
+    const bf16x8 v01 = *reinterpret_cast<const bf16x8 *>(src + C);
+    const bf16x8 v10 = *reinterpret_cast<const bf16x8 *>(src + (size_t)W * C);
+    const bf16x8 v11 = *reinterpret_cast<const bf16x8 *>(src + (size_t)W * C + C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
+    *reinterpret_cast<bf16x8 *>(y + po * C + gc * 8) = o;
+}
+
+// Backward of dropout(relu(.)) -> maxpool in one pass: the pooled gradient goes to the first
+// maximal position (scan order, as torch does) times (d > 0 ? scale : 0).
+__global__ void maxpool2_bwd_kernel(const bf16 *__restrict__ d, const bf16 *__restrict__ gy, int B, int H, int W, int C,
+                                    float scale, bf16 *__restrict__ gz)
+{
+    const int Ho = H / 2, Wo = W / 2, G = C / 8;
+    const size_t n = (size_t)B * Ho * Wo * G;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int gc = (int)(e % G);
+    const size_t po = e / G;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), b = (int)(po / ((size_t)Wo * Ho));
+    const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + gc * 8;
+    const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    bf16x8 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const bf16x8 *>(d + base + offs[k]);
+    const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gy + po * C + gc * 8);
+    bf16x8 o[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float m = (float)v[0][j];
+        int arg = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if ((float)v[k][j] > m) { m = (float)v[k][j]; arg = k; }
+        const float gv = (m > 0.f) ? (float)g[j] * scale : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k][j] = (bf16)((k == arg) ? gv : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x8 *>(gz + base + offs[k]) = o[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// Bilinear up-sampling with align_corners=True (nn.UpsamplingBilinear2d, icp_weight_policy.py:175-176).
+__device__ __forceinline__ void up_coord(int o, float r, int n_src, int &i0, int &i1, float &l0, float &l1)
+{
+    const float f = r * (float)o;
+    i0 = (int)f;
+    i1 = i0 + ((i0 < n_src - 1) ? 1 : 0);
+    l1 = f - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ void upsample_fwd_kernel(const bf16 *__restrict__ x, int B, int Hs, int Ws, int C, int Ho, int Wo,
+                                    bf16 *__restrict__ y)
+{
+    const int G = C / 8;
+    const size_t n = (size_t)B * Ho * Wo * G;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int gc = (int)(e % G);
+    const size_t po = e / G;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), b = (int)(po / ((size_t)Wo * Ho));
+    const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    up_coord(yo, rh, Hs, y0, y1, ly0, ly1);
+    up_coord(xo, rw, Ws, x0, x1, lx0, lx1);
+    const bf16 *base = x + (size_t)b * Hs * Ws * C + gc * 8;
+    const bf16x8 a00 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y0 * Ws + x0) * C);
+    const bf16x8 a01 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y0 * Ws + x1) * C);
+    const bf16x8 a10 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y1 * Ws + x0) * C);
+    const bf16x8 a11 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y1 * Ws + x1) * C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (bf16)(ly0 * (lx0 * (float)a00[j] + lx1 * (float)a01[j]) + ly1 * (lx0 * (float)a10[j] + lx1 * (float)a11[j]));
+    *reinterpret_cast<bf16x8 *>(y + po * C + gc * 8) = o;
+}
+
+// Gather form of the adjoint (deterministic, no atomics): each source pixel sums the output
+// pixels it was interpolated into; optional ReLU/dropout factor of the source activation.
+__global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, int Ws, int C, int Ho, int Wo,
+                                    const bf16 *__restrict__ relu_src, float scale, bf16 *__restrict__ gx)
+{
+    const int G = C / 8;
+    const size_t n = (size_t)B * Hs * Ws * G;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int gc = (int)(e % G);
+    const size_t ps = e / G;
+    const int xs = (int)(ps % Ws), ys = (int)((ps / Ws) % Hs), b = (int)(ps / ((size_t)Ws * Hs));
+    const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    const int ylo = (rh > 0.f) ? max(0, (int)floorf((float)(ys - 1) / rh) - 1) : 0;
+    const int yhi = (rh > 0.f) ? min(Ho - 1, (int)ceilf((float)(ys + 1) / rh) + 1) : Ho - 1;
+    const int xlo = (rw > 0.f) ? max(0, (int)floorf((float)(xs - 1) / rw) - 1) : 0;
+    const int xhi = (rw > 0.f) ? min(Wo - 1, (int)ceilf((float)(xs + 1) / rw) + 1) : Wo - 1;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int yo = ylo; yo <= yhi; ++yo) {
+        int y0, y1;
+        float l0, l1;
+        up_coord(yo, rh, Hs, y0, y1, l0, l1);
+        const float wy = ((y0 == ys) ? l0 : 0.f) + ((y1 == ys) ? l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int xo = xlo; xo <= xhi; ++xo) {
+            int x0, x1;
+            float m0, m1;
+            up_coord(xo, rw, Ws, x0, x1, m0, m1);
+            const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
+            if (wx == 0.f) continue;
+            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gy + (((size_t)b * Ho + yo) * Wo + xo) * C + gc * 8);
+            const float w = wy * wx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
+        }
+    }
+    bf16x8 o;
+    if (relu_src) {
+        const bf16x8 sv = *reinterpret_cast<const bf16x8 *>(relu_src + ps * C + gc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)sv[j] > 0.f) ? acc[j] * scale : 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+    }
+    *reinterpret_cast<bf16x8 *>(gx + ps * C + gc * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Final layer: Conv2d(8 -> 1, 1x1) + Sigmoid (icp_weight_policy.py:96-99,184), fp32 mask out.
+__global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                 size_t npix, float *__restrict__ mask)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * 8);
+    float acc = bias[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)v[j] * (float)(bf16)w[j];
+    mask[p] = 1.0f / (1.0f + expf(-acc));
+}
+
+__global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ mask, const float *__restrict__ gmask,
+                                                        size_t npix, float scale, bf16 *__restrict__ gx,
+                                                        float *__restrict__ dW, float *__restrict__ db)
+{
+    __shared__ float red[4][9];
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float wv8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv8[j] = (float)(bf16)w[j];
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const float m = mask[p];
+        const float gl = gmask[p] * m * (1.0f - m);
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (float)v[j];
+            o[j] = (bf16)((xv > 0.f) ? gl * wv8[j] * scale : 0.f);
+            acc[j] += gl * xv;
+        }
+        acc[8] += gl;
+        *reinterpret_cast<bf16x8 *>(gx + p * 8) = o;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 8) atomicAdd(&dW[threadIdx.x], v);
+        else atomicAdd(&db[0], v);
+    }
+}
+
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
 
 }  // namespace
@@ -538,6 +827,96 @@ extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t 
     const int n = cout * cin * 9;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dWt, cout, cin,
                        accumulate, dW);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+static unsigned nblk(size_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, int32_t B, int32_t H,
+                              int32_t Wd, void *y, void *stream)
+{
+    MMK_REQUIRE(x && W && y, "mmk_conv_first: NULL pointer");
+    MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first: bad shape (cin must be 1..4)");
+    const size_t npix = (size_t)B * H * Wd;
+    const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 8192);
+    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, B, H, Wd, (bf16 *)y);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, int32_t B, int32_t H, int32_t Wd,
+                                    float *dW, float *db, void *stream)
+{
+    MMK_REQUIRE(x && g && dW, "mmk_conv_first_wgrad: NULL pointer");
+    MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first_wgrad: bad shape");
+    const size_t npix = (size_t)B * H * Wd;
+    const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 1024);
+    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B, H,
+                       Wd, dW, db);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *stream)
+{
+    MMK_REQUIRE(x && y && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "mmk_maxpool2_fwd: bad argument");
+    const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, H, W, C,
+                       (bf16 *)y);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
+                                void *gz, void *stream)
+{
+    MMK_REQUIRE(d && gy && gz && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "mmk_maxpool2_bwd: bad argument");
+    const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)d,
+                       (const bf16 *)gy, B, H, W, C, scale, (bf16 *)gz);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo, void *y,
+                                void *stream)
+{
+    MMK_REQUIRE(x && y && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_fwd: bad argument");
+    const size_t n = (size_t)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, Hs, Ws, C,
+                       Ho, Wo, (bf16 *)y);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo,
+                                const void *relu_src, float scale, void *gx, void *stream)
+{
+    MMK_REQUIRE(gy && gx && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_bwd: bad argument");
+    const size_t n = (size_t)B * Hs * Ws * (C / 8);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, B, Hs, Ws, C,
+                       Ho, Wo, (const bf16 *)relu_src, scale, (bf16 *)gx);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_final_fwd(const void *x, const float *w, const float *bias, int64_t npix, float *mask, void *stream)
+{
+    MMK_REQUIRE(x && w && bias && mask && npix >= 1, "mmk_final_fwd: bad argument");
+    hipLaunchKernelGGL(final_fwd_kernel, dim3(nblk((size_t)npix, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w,
+                       bias, (size_t)npix, mask);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
+                             void *gx, float *dW, float *db, void *stream)
+{
+    MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && npix >= 1, "mmk_final_bwd: bad argument");
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 2048);
+    hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
+                       (size_t)npix, scale, (bf16 *)gx, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -77,6 +77,10 @@ class LearnICPWeightPolicy(nn.Module):
         # conv compute dtype: bf16 MFMA through MIOpen on a HIP device, fp32 masters
         self.amp_dtype = params.get("amp_dtype", torch.bfloat16)
         self.channels_last = params.get("channels_last", True)
+        # "hip": hand-written NHWC bf16 kernels (csrc/mmk_unet.hip) for the reference's default
+        # network configuration; "torch": nn.Conv2d on MIOpen (leaky ReLU / batch norm variants)
+        self.unet_backend = params.get("unet_backend", "hip")
+        self._step = 0
 
         self.mean_num_pts = 0.0
         self.max_w = 0.0
@@ -163,7 +167,15 @@ class LearnICPWeightPolicy(nn.Module):
         map_pc = batch_map["pc"].to(self.device)
 
         if override_mask is None:
-            weight_mask = self._unet(self._network_input(fft_data, fft_cfar))
+            net_in = self._network_input(fft_data, fft_cfar)
+            use_hip = (self.unet_backend == "hip" and net_in.is_cuda and not self.leaky and not self.batch_norm
+                       and net_in.shape[1] <= 4 and net_in.shape[2] % 32 == 0 and net_in.shape[3] % 32 == 0)
+            if use_hip:
+                from . import unet_hip
+                self._step += 1
+                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step)
+            else:
+                weight_mask = self._unet(net_in)
         else:
             weight_mask = override_mask.to(self.device)
 

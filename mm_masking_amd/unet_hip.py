@@ -73,3 +73,256 @@ def wgrad_unpack(dWt, accumulate_into=None):
     _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack(_p(dWt), cout, cin, 1 if accumulate_into is not None else 0, _p(out),
                                                    _lib.stream_ptr(dWt.device)))
     return out
+
+
+# ----------------------------------------------------------------------------- small wrappers
+def _sp(dev):
+    return _lib.stream_ptr(dev)
+
+
+def conv_first(x, w, b):
+    """x fp32 (B,cin,H,W) -> bf16 (B,H,W,8), + bias + ReLU (encoder.0.0)."""
+    B, cin, H, W = x.shape
+    y = torch.empty(B, H, W, 8, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mmk_conv_first(_p(x), cin, _p(w), _p(b), B, H, W, _p(y), _sp(x.device)))
+    return y
+
+
+def maxpool2(x):
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mmk_maxpool2_fwd(_p(x), B, H, W, C, _p(y), _sp(x.device)))
+    return y
+
+
+def maxpool2_bwd(d, gy, scale):
+    B, H, W, C = d.shape
+    gz = torch.empty_like(d)
+    _lib.check(_lib.lib().mmk_maxpool2_bwd(_p(d), _p(gy), B, H, W, C, float(scale), _p(gz), _sp(d.device)))
+    return gz
+
+
+def upsample(x, Ho, Wo):
+    B, Hs, Ws, C = x.shape
+    y = torch.empty(B, Ho, Wo, C, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mmk_upsample_fwd(_p(x), B, Hs, Ws, C, Ho, Wo, _p(y), _sp(x.device)))
+    return y
+
+
+def upsample_bwd(gy, Hs, Ws, relu_src=None, scale=1.0):
+    B, Ho, Wo, C = gy.shape
+    gx = torch.empty(B, Hs, Ws, C, dtype=BF16, device=gy.device)
+    _lib.check(_lib.lib().mmk_upsample_bwd(_p(gy), B, Hs, Ws, C, Ho, Wo, _p(relu_src), float(scale), _p(gx),
+                                           _sp(gy.device)))
+    return gx
+
+
+def final_fwd(x, w, b):
+    B, H, W, _ = x.shape
+    mask = torch.empty(B, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mmk_final_fwd(_p(x), _p(w), _p(b), B * H * W, _p(mask), _sp(x.device)))
+    return mask
+
+
+# ----------------------------------------------------------------------------- the fused network
+DEBUG = None      # set to a dict to capture the backward pass's gradient tensors (tests/diagnostics)
+ENC = ["encoder.%d" % i for i in range(6)]
+DEC = ["decoder.%d" % i for i in range(5)]
+
+
+def param_list(module):
+    """Parameters in state_dict order: encoder.{0..5}.{0,2}, decoder.{0..4}.{0,2}, final_layer.0."""
+    out = []
+    for blk in list(module.encoder) + list(module.decoder):
+        out += [blk[0].weight, blk[0].bias, blk[2].weight, blk[2].bias]
+    out += [module.final_layer[0].weight, module.final_layer[0].bias]
+    return out
+
+
+class _UNet(torch.autograd.Function):
+    """mask = sigmoid(final(decoder(encoder(x)))) with every layer in hand-written HIP;
+    backward is the hand-scheduled reverse pass (no autograd graph inside)."""
+
+    @staticmethod
+    def forward(ctx, x, drop_p, seed, training, *params):
+        dev = x.device
+        x = x.contiguous().float()
+        B, cin, H, W = x.shape
+        P = [p.detach() for p in params]
+
+        def wb(k):                 # conv k: 0..11 encoder (2 per block), 12..21 decoder, 22 final
+            return P[2 * k], P[2 * k + 1]
+
+        p_drop = float(drop_p) if training else 0.0
+        ctr = [int(seed) * 64]
+
+        def next_seed():
+            ctr[0] += 1
+            return ctr[0]
+
+        packs = {}
+
+        def pk(k):
+            if k not in packs:
+                packs[k] = pack_weights(wb(k)[0])
+            return packs[k]
+
+        saved = {}
+        # ---- encoder
+        w0, b0 = wb(0)
+        a = conv_first(x, w0.float().contiguous(), b0.float().contiguous())
+        w1, b1 = wb(1)
+        d = conv3x3(a, pk(1), 8, bias=b1, relu=True, drop_p=p_drop, seed=next_seed())
+        saved["e0"] = (a, d)
+        t = [d]                                   # t[i] = input of encoder block i+1 / skip tensors
+        ch = [8, 16, 32, 64, 128, 256]
+        for i in range(1, 6):
+            wa, ba = wb(2 * i)
+            wc, bc = wb(2 * i + 1)
+            a = conv3x3(t[i - 1], pk(2 * i), ch[i], bias=ba, relu=True)
+            d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed())
+            t.append(maxpool2(d))
+            saved["e%d" % i] = (a, d)
+        # ---- decoder
+        cur = t[5]
+        dsaved = []
+        for j in range(5):
+            skip = t[4 - j]
+            cs = skip.shape[3]
+            k0, k1 = 12 + 2 * j, 13 + 2 * j
+            _, b_a = wb(k0)
+            _, b_c = wb(k1)
+            u = upsample(cur, skip.shape[1], skip.shape[2])
+            a1 = conv3x3(u, pk(k0), cs, bias=b_a, relu=True)
+            d1 = conv3x3(a1, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed())
+            a2 = conv3x3(skip, pk(k0), cs, bias=b_a, x2=d1, relu=True)
+            d2 = conv3x3(a2, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed())
+            dsaved.append((u, a1, d1, a2, d2))
+            cur = d2
+        wf, bf = wb(22)
+        wf8 = wf.float().reshape(8).contiguous()
+        mask = final_fwd(cur, wf8, bf.float().contiguous())
+        if DEBUG is not None:
+            DEBUG["fwd"] = {"t": t, "enc": saved, "dec": dsaved}
+        ctx.x = x
+        ctx.t = t
+        ctx.saved_enc = saved
+        ctx.saved_dec = dsaved
+        ctx.P = P
+        ctx.mask = mask
+        ctx.scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        ctx.n_params = len(params)
+        return mask
+
+    @staticmethod
+    def backward(ctx, gmask):
+        L = _lib.lib()
+        x, t, P = ctx.x, ctx.t, ctx.P
+        dev = x.device
+        s = ctx.scale
+        B = x.shape[0]
+        gmask = gmask.contiguous().float()
+
+        def W(k):
+            return P[2 * k]
+
+        packs_t = {}
+
+        def pkt(k):
+            if k not in packs_t:
+                packs_t[k] = pack_weights(W(k), transposed=True)
+            return packs_t[k]
+
+        dWt, dB = {}, {}
+
+        def grads(k):
+            if k not in dWt:
+                cout, cin = W(k).shape[0], W(k).shape[1]
+                dWt[k] = torch.zeros(9, cout, cin, dtype=torch.float32, device=dev)
+                dB[k] = torch.zeros(cout, dtype=torch.float32, device=dev)
+            return dWt[k], dB[k]
+
+        def wgrad(k, x1, g, x2=None):
+            dw, db = grads(k)
+            conv3x3_wgrad(x1, g, W(k).shape[0], x2=x2, dWt=dw, db=db)
+
+        # ---- final layer
+        u4, a1_4, d1_4, a2_4, d2_4 = ctx.saved_dec[4]
+        wf8 = W(22).float().reshape(8).contiguous()
+        g_fw = torch.zeros(8, dtype=torch.float32, device=dev)
+        g_fb = torch.zeros(1, dtype=torch.float32, device=dev)
+        gz = torch.empty_like(d2_4)
+        _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, _p(gz), _p(g_fw),
+                                   _p(g_fb), _sp(dev)))
+        dbg = DEBUG
+        if dbg is not None:
+            dbg["gz_d2_4"] = gz
+        # ---- decoder, j = 4..0
+        g_skip = [None] * 5            # gradient w.r.t. t[i], i = 0..4, written by the decoder
+        g_t5 = None
+        for j in range(4, -1, -1):
+            u, a1, d1, a2, d2 = ctx.saved_dec[j]
+            skip = t[4 - j]
+            cs = skip.shape[3]
+            cin_first = u.shape[3]
+            k0, k1 = 12 + 2 * j, 13 + 2 * j
+            # second application
+            wgrad(k1, a2, gz)
+            gz_a2 = conv3x3(gz, pkt(k1), cs, relu_src=a2, scale=1.0)
+            wgrad(k0, skip, gz_a2, x2=d1)
+            # skip of dec4 is the post-dropout activation of encoder block 0: apply its factor here
+            skip_is_act = (j == 4)
+            gsk, gz_d1 = conv3x3(gz_a2, pkt(k0), 2 * cs, split=cs, relu_src=skip if skip_is_act else None,
+                                 scale=s, relu_src2=d1, scale2=s)
+            g_skip[4 - j] = gsk
+            # first application
+            wgrad(k1, a1, gz_d1)
+            gz_a1 = conv3x3(gz_d1, pkt(k1), cs, relu_src=a1, scale=1.0)
+            wgrad(k0, u, gz_a1)
+            g_u = conv3x3(gz_a1, pkt(k0), cin_first)
+            if dbg is not None:
+                dbg["gz_a2_%d" % j], dbg["gz_d1_%d" % j], dbg["gz_a1_%d" % j] = gz_a2, gz_d1, gz_a1
+                dbg["g_u_%d" % j], dbg["g_skip_%d" % j] = g_u, gsk.clone()
+            if j > 0:
+                prev_d2 = ctx.saved_dec[j - 1][4]
+                gz = upsample_bwd(g_u, prev_d2.shape[1], prev_d2.shape[2], relu_src=prev_d2, scale=s)
+            else:
+                g_t5 = upsample_bwd(g_u, t[5].shape[1], t[5].shape[2])
+        # ---- encoder, i = 5..1
+        g_t = g_t5
+        for i in range(5, 0, -1):
+            a, d = ctx.saved_enc["e%d" % i]
+            gz_d = maxpool2_bwd(d, g_t, s)
+            if dbg is not None:
+                dbg["g_t_%d" % i], dbg["gz_d_e%d" % i] = g_t.clone(), gz_d
+            wgrad(2 * i + 1, a, gz_d)
+            gz_a = conv3x3(gz_d, pkt(2 * i + 1), a.shape[3], relu_src=a, scale=1.0)
+            wgrad(2 * i, t[i - 1], gz_a)
+            tgt = g_skip[i - 1]
+            cin_i = t[i - 1].shape[3]
+            if i == 1:      # t[0] is an activation: factor on the dgrad, then accumulate
+                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True, relu_src=t[0], scale=s)
+            else:
+                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True)
+            g_t = tgt
+        # ---- encoder block 0
+        a0, d0 = ctx.saved_enc["e0"]
+        gz_d0 = g_t
+        wgrad(1, a0, gz_d0)
+        gz_a0 = conv3x3(gz_d0, pkt(1), 8, relu_src=a0, scale=1.0)
+        cin0 = x.shape[1]
+        g_w0 = torch.zeros(8, cin0, 3, 3, dtype=torch.float32, device=dev)
+        g_b0 = torch.zeros(8, dtype=torch.float32, device=dev)
+        _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0), _sp(dev)))
+        # ---- assemble parameter gradients in input order
+        out = [g_w0, g_b0]
+        for k in range(1, 22):
+            out += [wgrad_unpack(dWt[k]), dB[k]]
+        out += [g_fw.reshape(1, 8, 1, 1), g_fb]
+        out = [g.to(p.dtype) for g, p in zip(out, P)]
+        return (None, None, None, None) + tuple(out)
+
+
+def unet_mask(module, x, training, seed):
+    """sigmoid mask (B,H,W) fp32 of the module's network on fp32 NCHW input x."""
+    return _UNet.apply(x, float(module.dropout), int(seed), bool(training), *param_list(module))

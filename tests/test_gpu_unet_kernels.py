@@ -123,3 +123,207 @@ def test_conv3x3_wgrad_concat():
     y.backward(gy.float().permute(0, 3, 1, 2))
     dW = uh.wgrad_unpack(uh.conv3x3_wgrad(xa, gy, 8, x2=xb))
     assert (dW - w.grad).abs().max().item() < 2e-3 * w.grad.abs().max().item() + 1e-3
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def test_aux_kernels_vs_torch():
+    g = torch.Generator().manual_seed(0)
+    # first layer
+    x = torch.rand(2, 3, 20, 36, generator=g).to(DEV)
+    w = (torch.randn(8, 3, 3, 3, generator=g) / 5).to(DEV)
+    b = torch.randn(8, generator=g).to(DEV)
+    y = uh.conv_first(x, w, b)
+    ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), b, padding=1)).permute(0, 2, 3, 1)
+    assert (y.float() - ref).abs().max().item() < 0.03
+    # max pool fwd / bwd (with the fused relu+dropout factor)
+    d = F.relu(torch.randn(2, 16, 12, 20, generator=g)).to(DEV)
+    dn = _nhwc(d)
+    p = uh.maxpool2(dn)
+    dref = dn.float().permute(0, 3, 1, 2).requires_grad_(True)
+    pref = F.max_pool2d(dref, 2, 2)
+    assert torch.equal(p.float(), pref.permute(0, 2, 3, 1))
+    gy = torch.randn(2, 16, 6, 10, generator=g).to(DEV)
+    pref.backward(gy.to(torch.bfloat16).float())
+    gz = uh.maxpool2_bwd(dn, _nhwc(gy), 1.25)
+    want = (dref.grad * (dref > 0) * 1.25).permute(0, 2, 3, 1)
+    assert (gz.float() - want).abs().max().item() < 0.02
+    # bilinear upsample (align_corners) fwd / bwd
+    for (hs, ws, ho, wo) in [(20, 20, 40, 40), (5, 7, 10, 14), (40, 40, 80, 80), (6, 6, 13, 11)]:
+        xs = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
+        xr = xs.to(torch.bfloat16).float().requires_grad_(True)
+        ur = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=True)
+        u = uh.upsample(_nhwc(xs), ho, wo)
+        assert (u.float() - ur.permute(0, 2, 3, 1)).abs().max().item() < 0.02
+        gu = torch.randn(2, 8, ho, wo, generator=g).to(DEV)
+        ur.backward(gu.to(torch.bfloat16).float())
+        gx = uh.upsample_bwd(_nhwc(gu), hs, ws)
+        assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.05
+        src = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
+        gx2 = uh.upsample_bwd(_nhwc(gu), hs, ws, relu_src=_nhwc(src), scale=2.0)
+        want = (xr.grad * (src.to(torch.bfloat16).float() > 0) * 2.0).permute(0, 2, 3, 1)
+        assert (gx2.float() - want).abs().max().item() < 0.1
+    # final layer
+    xf = F.relu(torch.randn(2, 8, 10, 12, generator=g)).to(DEV)
+    wf = torch.randn(8, generator=g).to(DEV)
+    bf = torch.randn(1, generator=g).to(DEV)
+    m = uh.final_fwd(_nhwc(xf), wf, bf)
+    mref = torch.sigmoid((xf.to(torch.bfloat16).float() * wf.to(torch.bfloat16).float().view(1, 8, 1, 1)).sum(1) + bf)
+    assert (m - mref).abs().max().item() < 1e-4
+
+
+def _policy(dropout, amp):
+    from mm_masking_amd import train_icp_weights as trn
+    from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+    p = trn.default_params(DEV)
+    p.update({"dropout": dropout, "amp_dtype": amp, "unet_backend": "torch"})
+    torch.manual_seed(11)
+    return LearnICPWeightPolicy(p).to(DEV)
+
+
+class _Q(torch.autograd.Function):
+    """bf16 storage point: rounds the tensor in forward and its gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _emulated_unet(model, x):
+    """fp32 PyTorch network with bf16 rounding at exactly the points where the HIP path stores
+    bf16 tensors (activations forward, gradient tensors backward)."""
+    q = _Q.apply
+
+    def conv(t, m):
+        return q(F.relu(F.conv2d(t, m.weight.to(torch.bfloat16).float(), m.bias, padding=1)))
+
+    t = [None] * 6
+    xb = x.to(torch.bfloat16).float()
+    cur = conv(conv(xb, model.encoder[0][0]), model.encoder[0][2])
+    t[0] = cur
+    for i in range(1, 6):
+        cur = conv(conv(t[i - 1], model.encoder[i][0]), model.encoder[i][2])
+        t[i] = F.max_pool2d(cur, 2, 2)
+    cur = t[5]
+    for j in range(5):
+        skip = t[4 - j]
+        u = q(F.interpolate(cur, size=skip.shape[2:], mode="bilinear", align_corners=True))
+        d1 = conv(conv(u, model.decoder[j][0]), model.decoder[j][2])
+        cur = conv(conv(torch.cat([skip, d1], 1), model.decoder[j][0]), model.decoder[j][2])
+    fl = model.final_layer[0]
+    return torch.sigmoid(F.conv2d(cur, fl.weight.to(torch.bfloat16).float(), fl.bias)).squeeze(1)
+
+
+def _nchw(t):
+    return t.float().permute(0, 3, 1, 2)
+
+
+def _forced(z_or_y, mine_nhwc, relu, scale=1.0):
+    """Forward value := the HIP path's stored tensor; backward := the reference operator's
+    (ReLU mask taken from the stored tensor, as the HIP epilogues do), rounded to bf16."""
+    mine = _nchw(mine_nhwc)
+    y = z_or_y * (mine > 0) * scale if relu else z_or_y
+    return _Q.apply(y + (mine - y).detach())
+
+
+def _unet_on_hip_activations(model, x, fwd, drop=0.0):
+    """fp32 PyTorch autograd graph of the network whose every stored tensor is pinned to the
+    value the HIP forward produced: all discrete decisions (ReLU masks, pool arg-max) coincide,
+    so parameter gradients must agree up to bf16 rounding of the gradient tensors."""
+    sd = 1.0 / (1.0 - drop)       # inverted-dropout scale of the second conv of every block
+
+    def conv(t, m, mine, scale=1.0):
+        return _forced(F.conv2d(t, m.weight.to(torch.bfloat16).float(), m.bias, padding=1), mine, True, scale)
+
+    t = [None] * 6
+    xb = x.to(torch.bfloat16).float()
+    a0, d0 = fwd["enc"]["e0"]
+    t[0] = conv(conv(xb, model.encoder[0][0], a0), model.encoder[0][2], d0, sd)
+    for i in range(1, 6):
+        a, d = fwd["enc"]["e%d" % i]
+        t[i] = F.max_pool2d(conv(conv(t[i - 1], model.encoder[i][0], a), model.encoder[i][2], d, sd), 2, 2)
+    cur = t[5]
+    for j in range(5):
+        u_m, a1_m, d1_m, a2_m, d2_m = fwd["dec"][j]
+        skip = t[4 - j]
+        u = _forced(F.interpolate(cur, size=skip.shape[2:], mode="bilinear", align_corners=True), u_m, False)
+        d1 = conv(conv(u, model.decoder[j][0], a1_m), model.decoder[j][2], d1_m, sd)
+        cur = conv(conv(torch.cat([skip, d1], 1), model.decoder[j][0], a2_m), model.decoder[j][2], d2_m, sd)
+    fl = model.final_layer[0]
+    return torch.sigmoid(F.conv2d(cur, fl.weight.to(torch.bfloat16).float(), fl.bias)).squeeze(1)
+
+
+@pytest.mark.parametrize("H,drop", [(64, 0.0), (160, 0.0), (96, 0.1)])
+def test_unet_hip_backward_exact_on_pinned_activations(H, drop):
+    model = _policy(drop, torch.float32)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 1, H, H, generator=g).to(DEV)
+    gsel = torch.randn(2, H, H, generator=g).to(DEV)
+    uh.DEBUG = {}
+    try:
+        out = uh.unet_mask(model, x, training=True, seed=5)
+        (out * gsel).sum().backward()
+        fwd = uh.DEBUG["fwd"]
+    finally:
+        uh.DEBUG = None
+    got = [p.grad.clone() for p in uh.param_list(model)]
+    model.zero_grad()
+    ref = _unet_on_hip_activations(model, x, fwd, drop)
+    assert (out - ref).abs().max().item() < 1e-4
+    (ref * gsel).sum().backward()
+    names = [n for n, _ in model.named_parameters()]
+    for n, a, p in zip(names, got, uh.param_list(model)):
+        rel = ((a - p.grad).norm() / (p.grad.norm() + 1e-12)).item()
+        assert rel < 0.03, (n, rel)
+
+
+def test_unet_hip_dropout_backward_scale():
+    """With dropout the stored activation is d = relu(z) * m / (1-p); the backward factor is
+    (d > 0 ? 1/(1-p) : 0).  Checked on one conv + dropout stage against autograd."""
+    B, H, W, p = 2, 32, 64, 0.2
+    x = _rand_nhwc(B, H, W, 16, 3)
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(16, 16, 3, 3, generator=g) / 12).to(DEV)
+    wp, wpt = uh.pack_weights(w), uh.pack_weights(w, transposed=True)
+    d = uh.conv3x3(x, wp, 16, relu=True, drop_p=p, seed=77)
+    gy = _rand_nhwc(B, H, W, 16, 4)
+    # gradient w.r.t. the pre-activation, as every producer kernel forms it
+    gz = (gy.float() * torch.where(d.float() > 0, 1.0 / (1 - p), 0.0)).to(torch.bfloat16)
+    gx = uh.conv3x3(gz, wpt, 16)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    z = F.relu(F.conv2d(xr, w.to(torch.bfloat16).float(), padding=1))
+    m = (d.float().permute(0, 3, 1, 2) > 0).float() / (1 - p)       # the kernel's keep mask (where relu > 0)
+    (z * m).backward(gy.float().permute(0, 3, 1, 2))
+    assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.06
+
+
+def test_unet_hip_close_to_fp32_module():
+    """Against the plain fp32 nn.Module on MIOpen: bf16 storage perturbs this random-init
+    network's gradients by tens of percent per tensor (PyTorch's own bf16 autocast path
+    deviates more: scripts/diag_unet_grads.py), so only direction and global error are bounded."""
+    H = 64
+    model = _policy(0.0, torch.float32)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 1, H, H, generator=g).to(DEV)
+    gsel = torch.randn(2, H, H, generator=g).to(DEV)
+    ref = model._unet(x.clone())
+    (ref * gsel).sum().backward()
+    gref = [p.grad.clone() for p in uh.param_list(model)]
+    model.zero_grad()
+    out = uh.unet_mask(model, x, training=True, seed=0)
+    (out * gsel).sum().backward()
+    assert (out - ref).abs().max().item() < 5e-3
+    got = [p.grad for p in uh.param_list(model)]
+    num = sum(((a - b) ** 2).sum().item() for a, b in zip(got, gref))
+    den = sum((b ** 2).sum().item() for b in gref)
+    assert num <= (0.12 ** 2) * den
+    for a, b in zip(got, gref):
+        assert F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.8
