@@ -45,6 +45,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak
+UNET_GFLOP_FWD_PER_SAMPLE = 28.85  # SURVEY.md §8a Group U (hooked on the reference module); fwd+bwd = 3x
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
 N_PAD, M_VALID, M_PAD, DIM, ICP_ITERS = 5120, 20000, 20480, 2, 10
 
@@ -94,6 +96,32 @@ def cpu_baseline(params_like, sample_pairs=4, timed_steps=3):
             "sample": "%d timed steps of B=%d after 1 warm-up (fp32 U-Net + 10-iter pt2pl Huber ICP fwd+bwd + Adam; "
                       "CFAR/polar->Cartesian outside the step as in the reference's cached Dataset), %.1f s"
                       % (timed_steps, sample_pairs, dt)}
+
+
+def conv_stack_rate(model, raw, params, device, reps=3):
+    """MFMA leg of the measurement: the mask U-Net alone (forward + backward), HIP events on
+    the current stream, against the dense bf16 MFMA peak."""
+    from mm_masking_amd import train_icp_weights as trn
+    batch = trn.prepare_batch(raw, params, max_loc_pts=N_PAD)
+    B = batch["loc_data"]["fft_data"].shape[0]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    f_ms, b_ms = [], []
+    for _ in range(reps + 1):
+        model.zero_grad(set_to_none=True)
+        ev[0].record()
+        mask = model(batch["loc_data"], batch["map_data"], None, mask_only=True)
+        ev[1].record()
+        mask.sum().backward()
+        ev[2].record()
+        torch.cuda.synchronize(device)
+        f_ms.append(ev[0].elapsed_time(ev[1]))
+        b_ms.append(ev[1].elapsed_time(ev[2]))
+    f, b = min(f_ms[1:]), min(b_ms[1:])
+    tf = 3 * UNET_GFLOP_FWD_PER_SAMPLE * B / (f + b)          # GFLOP / ms = TFLOP/s
+    return {"bound": "mfma", "unet_fwd_ms": f, "unet_bwd_ms": b, "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+            "flop": "3 x 28.85 GFLOP/sample (fwd + data grad + weight grad), B=%d" % B,
+            "note": "layers with <= 16 channels at 640x640 are HBM-bound (arithmetic intensity ~70 FLOP/B)"}
 
 
 def pose_parity(model, params, device, pairs=2):
@@ -223,7 +251,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: train_icp_weights step fwd+bwd, batch=%d per GPU, 10 dICP "
                                    "iters, point-to-plane Huber, dim=2; 400x3360 polar radar -> GO-CFAR + peaks + "
-                                   "polar->Cartesian 640x640 -> U-Net (bf16 convs, fp32 masters) -> dICP (fp32 points, "
+                                   "polar->Cartesian 640x640 -> U-Net (hand-written NHWC bf16 MFMA kernels, fp32 masters) -> dICP (fp32 points, "
                                    "fp64 normal equations) -> rot+trans+mask_pts loss -> Adam" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "scan_pts_pad": N_PAD, "map_pts": M_VALID,
                        "map_pts_pad": M_PAD, "icp_iters": ICP_ITERS, "parallelism": "dp%d" % world,
@@ -239,6 +267,8 @@ def main():
                                   "frac": evals * 6 / nn_avg_s / 1e12 / VALU_PEAK_TFLOPS,
                                   "flop_per_eval": 6}},
         }
+        if world == 1:
+            result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)
         if world == 1 and not args.no_parity:
             progress("pose parity vs the CPU restatement")
             result["pose_parity_vs_cpu_restatement"] = pose_parity(model, params, device)

@@ -29,6 +29,9 @@ constexpr int TH = 8, TW = 32;            // output pixels per block tile
 constexpr int HT = TH + 2, WT = TW + 2;   // halo tile
 constexpr int CONV_THREADS = 256;
 
+// LDS pixel pitch (elements): 16 bytes of padding de-correlates the banks of consecutive
+// pixels for the 16-byte fragment reads (a 128-byte pitch is an 8-way conflict).
+__host__ __device__ constexpr int lds_pitch(int c) { return c >= 16 ? c + 8 : c; }
 __host__ __device__ constexpr int ksteps(int ck) { return ck >= 32 ? 9 * (ck / 32) : (ck == 16 ? 5 : 3); }
 __host__ __device__ constexpr int cin_chunk(int cin) { return cin >= 64 ? 64 : cin; }
 __host__ __device__ constexpr int cout_group(int cout) { return cout >= 64 ? 64 : (cout <= 16 ? 16 : cout); }
@@ -131,8 +134,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
     constexpr int MT = CM / 16;
     constexpr int NT = 4;  // per wave: 2 tile rows x 2 halves of 16 pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);                       // HT*WT*CK
-    bf16 *w_lds = in_tile + HT * WT * CK;                                 // NS*MT*64*8
+    constexpr int PK = lds_pitch(CK);
+    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);                       // HT*WT*PK
+    bf16 *w_lds = in_tile + HT * WT * PK;                                 // NS*MT*64*8
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_x = (a.W + TW - 1) / TW;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
                 if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
                 else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
             }
-            *reinterpret_cast<uint4 *>(in_tile + (size_t)pix * CK + gc * 8) = v;
+            *reinterpret_cast<uint4 *>(in_tile + (size_t)pix * PK + gc * 8) = v;
         }
         // ---- stage this (group, chunk) block of packed weights
         {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int row = 2 * wv + (n >> 1), col = (n & 1) * 16 + (lane & 15);
-                bf[n] = *reinterpret_cast<const bf16x8 *>(in_tile + ((size_t)((row + ty) * WT + col + tx)) * CK + ch);
+                bf[n] = *reinterpret_cast<const bf16x8 *>(in_tile + ((size_t)((row + ty) * WT + col + tx)) * PK + ch);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
 template <int CK, int CM>
 int launch_conv(const ConvArgs &a, hipStream_t st)
 {
-    const size_t smem = ((size_t)HT * WT * CK + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
+    const size_t smem = ((size_t)HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
     if (smem > 64 * 1024)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
@@ -309,8 +313,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     constexpr int NTT = (CK >= 16) ? 9 * (CK / 16) : 5;  // n-tiles of 16 (tap, ci) columns
     constexpr int NTW = (NTT + 3) / 4;                    // per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // HT*WT*CK (+ pad)
-    bf16 *g_tile = x_tile + (HT * WT + 8) * CK;                    // TH*TW*CM (+ pad)
+    constexpr int PK = lds_pitch(CK);
+    bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // HT*WT*PK (+ pad)
+    bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // TH*TW*PG (+ pad)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chunk = blockIdx.y, group = blockIdx.z;
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     const int total_tiles = tiles_x * tiles_y * a.B;
     const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
     const int gcols = (a.COUT < CM) ? a.COUT : CM;   // valid columns of the g tile (COUT = 8 -> 8)
+    const int PG = lds_pitch(gcols);
 
     f32x4 acc[MT][NTW];
     f32x4 accb[MT];
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         }
         tap = tap > 8 ? 8 : tap;
         const int ty = tap / 3, tx = tap % 3;
-        b_off[n] = (unsigned)((((ty * WT) + 8 * g4 + q + tx) * CK + col) * 2);
+        b_off[n] = (unsigned)((((ty * WT) + 8 * g4 + q + tx) * PK + col) * 2);
     }
     const unsigned xbase = lds_addr(x_tile), gbase = lds_addr(g_tile);
 
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
                 if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
                 else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
             }
-            *reinterpret_cast<uint4 *>(x_tile + (size_t)pix * CK + gc * 8) = v;
+            *reinterpret_cast<uint4 *>(x_tile + (size_t)pix * PK + gc * 8) = v;
         }
         const int GPG = gcols / 8;
         for (int gi = tid; gi < TH * TW * GPG; gi += CONV_THREADS) {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
             uint4 v = make_uint4(0, 0, 0, 0);
             if (yy < a.H && xx < a.W)
                 v = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * a.COUT + group * CM + gc * 8);
-            *reinterpret_cast<uint4 *>(g_tile + (size_t)pix * gcols + gc * 8) = v;
+            *reinterpret_cast<uint4 *>(g_tile + (size_t)pix * PG + gc * 8) = v;
         }
         __syncthreads();
 #pragma unroll 1
@@ -383,15 +389,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
             i32x2 a_lo[MT], a_hi[MT], b_lo[NTW], b_hi[NTW];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const unsigned ad = gbase + (unsigned)(((r * TW + 8 * g4 + q) * gcols + m * 16 + 4 * pp) * 2);
+                const unsigned ad = gbase + (unsigned)(((r * TW + 8 * g4 + q) * PG + m * 16 + 4 * pp) * 2);
                 a_lo[m] = tr_read(ad);
-                a_hi[m] = tr_read(ad + (unsigned)(4 * gcols * 2));
+                a_hi[m] = tr_read(ad + (unsigned)(4 * PG * 2));
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-                const unsigned ad = xbase + b_off[n] + (unsigned)(r * WT * CK * 2);
+                const unsigned ad = xbase + b_off[n] + (unsigned)(r * WT * PK * 2);
                 b_lo[n] = tr_read(ad);
-                b_hi[n] = tr_read(ad + (unsigned)(4 * CK * 2));
+                b_hi[n] = tr_read(ad + (unsigned)(4 * PK * 2));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 template <int CK, int CM>
 int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
-    const size_t smem = ((size_t)(HT * WT + 8) * CK + (size_t)(TH * TW + 8) * CM) * sizeof(bf16);
+    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(CM)) * sizeof(bf16);
     if (smem > 64 * 1024)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
