@@ -26,7 +26,7 @@ def _params(**over):
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_unet_golden_fp32(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "unet.npz"), allow_pickle=False)
-    over = {"amp_dtype": torch.float32}
+    over = {"amp_dtype": torch.float32, "unet_backend": "torch"}
     if tag == "b":
         over.update({"cfar_input": True, "range_input": True, "leaky": True, "normalize": ["standardize"],
                      "log_transform": True})
@@ -51,10 +51,27 @@ def test_unet_golden_fp32(golden_dir, tag):
     np.testing.assert_allclose(ga, g["gabs_" + tag], rtol=2e-2, atol=1e-4)
 
 
+def test_unet_hip_backend_golden(golden_dir):
+    """The hand-written bf16 U-Net (default backend) against the reference module's golden mask."""
+    g = np.load(os.path.join(golden_dir, "unet.npz"), allow_pickle=False)
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(_params()).to(DEV)
+    assert model.unet_backend == "hip"
+    model.train()
+    scan = {"fft_data": torch.from_numpy(g["x_a"]), "fft_cfar": torch.from_numpy(g["cfar_a"]), "raw_pc": torch.zeros(2, 4, 3)}
+    m = model(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_a"], atol=2e-3)
+    (m * torch.from_numpy(g["gsel_a"]).to(DEV)).sum().backward()
+    names = [str(n) for n in g["names_a"]]
+    grads = dict(model.named_parameters())
+    ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
+    assert np.all(np.isfinite(ga)) and np.abs(ga / g["gabs_a"] - 1).max() < 0.6     # bf16 storage: see test_gpu_unet_kernels
+
+
 def test_unet_bf16_close_to_fp32():
     torch.manual_seed(7)
-    m32 = LearnICPWeightPolicy(_params(amp_dtype=torch.float32)).to(DEV)
-    m16 = LearnICPWeightPolicy(_params()).to(DEV)
+    m32 = LearnICPWeightPolicy(_params(amp_dtype=torch.float32, unet_backend="torch")).to(DEV)
+    m16 = LearnICPWeightPolicy(_params(unet_backend="torch")).to(DEV)
     m16.load_state_dict(m32.state_dict())
     x = torch.rand(2, 128, 128)
     scan = {"fft_data": x, "fft_cfar": x, "raw_pc": torch.zeros(2, 4, 3)}
@@ -105,7 +122,7 @@ def test_train_step_matches_cpu_port():
     """One full step (fp32 convs, no dropout) against the oracle's CPU port:
     same loss, same mask, same pose, parameter gradients close."""
     raw, params, batch = _small_batch(B=2, max_pts=2048)
-    params = dict(params, amp_dtype=torch.float32)
+    params = dict(params, amp_dtype=torch.float32, unet_backend="torch")
     torch.manual_seed(1234)
     model = LearnICPWeightPolicy(params).to(DEV)
     model.train()
