@@ -13,6 +13,7 @@
 // both operands are read from row-major [pixel][channel] LDS tiles with the transposing
 // ds_read_b64_tr_b16.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -241,6 +242,190 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
     }
 }
 
+// Software-pipelined, persistent form of the same convolution: a block walks the stages
+// (tile, input-channel chunk) of its share of the tiles; while the matrix cores work on the
+// stage that sits in LDS, the next stage's halo tile (and weight block, when it changes) is
+// already in flight from HBM/L2 into registers and is written to LDS after the barrier.
+template <int CK, int CM>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_pipe_kernel(const ConvArgs a, int total_tiles)
+{
+    constexpr int NS = ksteps(CK);
+    constexpr int MT = CM / 16;
+    constexpr int NT = 4;
+    constexpr int PK = lds_pitch(CK);
+    constexpr int GPP = CK / 8;
+    constexpr int NIN = HT * WT * GPP;           // 16-byte granules of the halo tile
+    constexpr int NW = NS * MT * 64;             // 16-byte granules of a weight block
+    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);
+    bf16 *w_lds = in_tile + HT * WT * PK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int group = blockIdx.y;
+    const int nchunk = a.CIN / CK;
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+
+    uint4 rin[RIN];
+    uint4 rw[RW];
+
+    auto load_in = [&](int t, int chunk) {
+        const int b = t / (tiles_x * tiles_y), tr = t % (tiles_x * tiles_y);
+        const int tx0 = (tr % tiles_x) * TW, ty0 = (tr / tiles_x) * TH;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int g = tid + i * CONV_THREADS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g < NIN) {
+                const int pix = g / GPP, gc = g % GPP;
+                const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
+                const int c = chunk * CK + gc * 8;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                    const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                    if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
+                    else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
+                }
+            }
+            rin[i] = v;
+        }
+    };
+    auto load_w = [&](int chunk) {
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NS * MT * 512);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * CONV_THREADS;
+            rw[i] = (g < NW) ? wsrc[g] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_in = [&]() {
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int g = tid + i * CONV_THREADS;
+            if (g < NIN) *reinterpret_cast<uint4 *>(in_tile + (size_t)(g / GPP) * PK + (g % GPP) * 8) = rin[i];
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * CONV_THREADS;
+            if (g < NW) reinterpret_cast<uint4 *>(w_lds)[g] = rw[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    int chunk = 0;
+    load_in(tile, 0);
+    load_w(0);
+    bool first = true;
+    while (true) {
+        store_in();
+        if (first || nchunk > 1) store_w();
+        first = false;
+        __syncthreads();
+        int ntile = tile, nck = chunk + 1;
+        if (nck == nchunk) {
+            nck = 0;
+            ntile = tile + gridDim.x;
+        }
+        const bool has_next = ntile < total_tiles;
+        if (has_next) {
+            load_in(ntile, nck);
+            if (nchunk > 1) load_w(nck);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            int tap, ch;
+            kslot<CK>(s, lane, tap, ch);
+            tap = tap > 8 ? 8 : tap;
+            const int ty = tap / 3, tx = tap % 3;
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = 2 * wv + (n >> 1), col = (n & 1) * 16 + (lane & 15);
+                bf[n] = *reinterpret_cast<const bf16x8 *>(in_tile + ((size_t)((row + ty) * WT + col + tx)) * PK + ch);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)((s * MT + m) * 64 + lane)) * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (chunk == nchunk - 1) {
+            const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+            const int tx0 = (tr % tiles_x) * TW, ty0 = (tr / tiles_x) * TH;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
+                if (c0 < a.COUT) {
+                    const bool firstp = c0 < a.o1.C;
+                    const ConvOutPart &o = firstp ? a.o1 : a.o2;
+                    const int cl = firstp ? c0 : c0 - a.o1.C;
+                    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bs[r] = a.bias[c0 + r];
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int yy = ty0 + 2 * wv + (n >> 1), xx = tx0 + (n & 1) * 16 + (lane & 15);
+                        if (yy < a.H && xx < a.W) {
+                            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = acc[m][n][r] + bs[r];
+                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            if (a.drop_p > 0.f) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    v[r] *= dropout_scale(a.seed, (unsigned)(p * a.COUT + c0 + r), a.drop_p, inv_keep);
+                            }
+                            bf16 *dst = o.y + p * o.C + cl;
+                            if (o.relu_src) {
+                                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o.relu_src + p * o.C + cl);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o.scale : 0.f;
+                            }
+                            if (o.accumulate) {
+                                const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+                            }
+                            bf16x4 outv;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
+                            *reinterpret_cast<bf16x4 *>(dst) = outv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        tile = ntile;
+        chunk = nck;
+    }
+}
+
+static int conv_variant()
+{
+    static const int v = [] { const char *e = getenv("MMK_CONV_VARIANT"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <int CK, int CM>
 int launch_conv(const ConvArgs &a, hipStream_t st)
 {
@@ -249,7 +434,19 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int groups = (a.COUT + CM - 1) / CM;
-    hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(tiles, groups, a.B), dim3(CONV_THREADS), smem, st, a);
+    if (conv_variant() == 0) {
+        hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(tiles, groups, a.B), dim3(CONV_THREADS), smem, st, a);
+    } else {
+        if (smem > 64 * 1024)
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_pipe_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        // persistent grid: as many blocks as the LDS footprint lets a CU hold, on 256 CUs
+        int per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
+        per_cu = per_cu < 1 ? 1 : per_cu;
+        const int total = tiles * a.B;
+        int gx = (256 * per_cu * conv_variant()) / groups;
+        gx = gx < 1 ? 1 : (gx > total ? total : gx);
+        hipLaunchKernelGGL((conv3x3_pipe_kernel<CK, CM>), dim3(gx, groups), dim3(CONV_THREADS), smem, st, a, total);
+    }
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -356,34 +553,67 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     }
     const unsigned xbase = lds_addr(x_tile), gbase = lds_addr(g_tile);
 
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    // register prefetch of the next tile's operands while the current one is consumed
+    constexpr int GPP = CK / 8;
+    constexpr int NIN = HT * WT * GPP;
+    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int GPGM = CM / 8;                                   // upper bound of granules per g pixel
+    constexpr int RG = (TH * TW * GPGM + CONV_THREADS - 1) / CONV_THREADS;
+    const int GPG = gcols / 8;
+    const int NG = TH * TW * GPG;
+    uint4 rin[RIN], rg[RG];
+    auto load_tile = [&](int t) {
         const int b = t / (tiles_x * tiles_y);
         const int tr = t % (tiles_x * tiles_y);
         const int tx0 = (tr % tiles_x) * TW, ty0 = (tr / tiles_x) * TH;
-        __syncthreads();
-        constexpr int GPP = CK / 8;
-        for (int gi = tid; gi < HT * WT * GPP; gi += CONV_THREADS) {
-            const int pix = gi / GPP, gc = gi % GPP;
-            const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
-            const int c = chunk * CK + gc * 8;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int gi = tid + i * CONV_THREADS;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
-                else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
+            if (gi < NIN) {
+                const int pix = gi / GPP, gc = gi % GPP;
+                const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
+                const int c = chunk * CK + gc * 8;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                    const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                    if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
+                    else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
+                }
             }
-            *reinterpret_cast<uint4 *>(x_tile + (size_t)pix * PK + gc * 8) = v;
+            rin[i] = v;
         }
-        const int GPG = gcols / 8;
-        for (int gi = tid; gi < TH * TW * GPG; gi += CONV_THREADS) {
-            const int pix = gi / GPG, gc = gi % GPG;
-            const int yy = ty0 + pix / TW, xx = tx0 + pix % TW;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gi = tid + i * CONV_THREADS;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy < a.H && xx < a.W)
-                v = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * a.COUT + group * CM + gc * 8);
-            *reinterpret_cast<uint4 *>(g_tile + (size_t)pix * PG + gc * 8) = v;
+            if (gi < NG) {
+                const int pix = gi / GPG, gc = gi % GPG;
+                const int yy = ty0 + pix / TW, xx = tx0 + pix % TW;
+                if (yy < a.H && xx < a.W)
+                    v = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * a.COUT + group * CM + gc * 8);
+            }
+            rg[i] = v;
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int gi = tid + i * CONV_THREADS;
+            if (gi < NIN) *reinterpret_cast<uint4 *>(x_tile + (size_t)(gi / GPP) * PK + (gi % GPP) * 8) = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gi = tid + i * CONV_THREADS;
+            if (gi < NG) *reinterpret_cast<uint4 *>(g_tile + (size_t)(gi / GPG) * PG + (gi % GPG) * 8) = rg[i];
+        }
+    };
+
+    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
         __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + (int)gridDim.x < total_tiles) load_tile(t + gridDim.x);
 #pragma unroll 1
         for (int r = 0; r < TH; ++r) {
             i32x2 a_lo[MT], a_hi[MT], b_lo[NTW], b_hi[NTW];
