@@ -787,7 +787,7 @@ struct NNPlan {
 // Tuning knobs of the NN kernel; MMK_NN_VARIANT = "<chunk>,<P>,<tiles_per_unit>" overrides
 // them for experiments (scripts/bench_nn.py).
 struct NNTune {
-    int chunk = 16, P = 2, tiles_per_unit = 2;
+    int chunk = 16, P = 2, tiles_per_unit = 5;
     NNTune()
     {
         if (const char *e = getenv("MMK_NN_VARIANT")) {

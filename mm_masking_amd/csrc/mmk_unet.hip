@@ -614,33 +614,47 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         store_tile();
         __syncthreads();
         if (t + (int)gridDim.x < total_tiles) load_tile(t + gridDim.x);
-#pragma unroll 1
-        for (int r = 0; r < TH; ++r) {
-            i32x2 a_lo[MT], a_hi[MT], b_lo[NTW], b_hi[NTW];
+        // fragments of tile row r+1 are fetched from LDS while the matrix cores consume row r
+        i32x2 fa[2][2 * MT], fb[2][2 * NTW];
+        auto issue_reads = [&](int r, i32x2 *ra, i32x2 *rb) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const unsigned ad = gbase + (unsigned)(((r * TW + 8 * g4 + q) * PG + m * 16 + 4 * pp) * 2);
-                a_lo[m] = tr_read(ad);
-                a_hi[m] = tr_read(ad + (unsigned)(4 * PG * 2));
+                ra[2 * m] = tr_read(ad);
+                ra[2 * m + 1] = tr_read(ad + (unsigned)(4 * PG * 2));
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
                 const unsigned ad = xbase + b_off[n] + (unsigned)(r * WT * PK * 2);
-                b_lo[n] = tr_read(ad);
-                b_hi[n] = tr_read(ad + (unsigned)(4 * PK * 2));
+                rb[2 * n] = tr_read(ad);
+                rb[2 * n + 1] = tr_read(ad + (unsigned)(4 * PK * 2));
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto consume = [&](const i32x2 *ra, const i32x2 *rb) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const bf16x8 af = frag_from(a_lo[m], a_hi[m]);
+                const bf16x8 af = frag_from(ra[2 * m], ra[2 * m + 1]);
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     if (wv + 4 * n < NTT)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(b_lo[n], b_hi[n]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(rb[2 * n], rb[2 * n + 1]), acc[m][n], 0, 0, 0);
                 }
                 if (wv == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0);
             }
+        };
+        issue_reads(0, fa[0], fb[0]);
+#pragma unroll 1
+        for (int r = 0; r < TH; r += 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            issue_reads(r + 1, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(fa[0], fb[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 2 < TH) issue_reads(r + 2, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(fa[1], fb[1]);
         }
     }
 
@@ -678,7 +692,11 @@ int launch_wgrad(const WgradArgs &a, hipStream_t st)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
     const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
-    int spatial = 768 / (chunks * groups);
+    // persistent grid sized to what the LDS footprint lets the 256 CUs hold: every extra block
+    // costs one more fp32 atomic pass over its dW slice (147 KB for a 64x64-channel slice)
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    int spatial = std::min(256 * per_cu, 768) / (chunks * groups);
     spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<CK, CM>), dim3(spatial, chunks, groups), dim3(CONV_THREADS), smem, st, a);
     MMK_LAUNCH_CHECK();
