@@ -128,126 +128,12 @@ __device__ __forceinline__ float dropout_scale(unsigned seed, unsigned e, float 
     return ((float)(h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
 }
 
+// Software-pipelined, persistent convolution: a block walks the stages (tile, input-channel
+// chunk) of its share of the tiles; while the matrix cores work on the stage that sits in
+// LDS, the next stage's halo tile (and weight block, when it changes) is already in flight
+// from HBM/L2 into registers and is written to LDS after the barrier.
 template <int CK, int CM>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a)
-{
-    constexpr int NS = ksteps(CK);
-    constexpr int MT = CM / 16;
-    constexpr int NT = 4;  // per wave: 2 tile rows x 2 halves of 16 pixels
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PK = lds_pitch(CK);
-    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);                       // HT*WT*PK
-    bf16 *w_lds = in_tile + HT * WT * PK;                                 // NS*MT*64*8
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tiles_x = (a.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
-    const int group = blockIdx.y, b = blockIdx.z;
-    const int nchunk = a.CIN / CK;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        if (chunk > 0) __syncthreads();
-        // ---- stage the input halo tile (zero padded), 16-byte granules of 8 channels
-        constexpr int GPP = CK / 8;
-        for (int g = tid; g < HT * WT * GPP; g += CONV_THREADS) {
-            const int pix = g / GPP, gc = g % GPP;
-            const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
-            const int c = chunk * CK + gc * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
-                else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
-            }
-            *reinterpret_cast<uint4 *>(in_tile + (size_t)pix * PK + gc * 8) = v;
-        }
-        // ---- stage this (group, chunk) block of packed weights
-        {
-            const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NS * MT * 512);
-            for (int g = tid; g < NS * MT * 64; g += CONV_THREADS) reinterpret_cast<uint4 *>(w_lds)[g] = wsrc[g];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            int tap, ch;
-            kslot<CK>(s, lane, tap, ch);
-            tap = tap > 8 ? 8 : tap;  // padded taps carry zero weights
-            const int ty = tap / 3, tx = tap % 3;
-            bf16x8 bf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int row = 2 * wv + (n >> 1), col = (n & 1) * 16 + (lane & 15);
-                bf[n] = *reinterpret_cast<const bf16x8 *>(in_tile + ((size_t)((row + ty) * WT + col + tx)) * PK + ch);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)((s * MT + m) * 64 + lane)) * 8);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: lane holds channels c0..c0+3 of pixel (row, col) for each (m, n)
-    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
-        if (c0 >= a.COUT) continue;
-        const bool first = c0 < a.o1.C;
-        const ConvOutPart &o = first ? a.o1 : a.o2;
-        const int cl = first ? c0 : c0 - a.o1.C;
-        float bs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[r] = a.bias[c0 + r];
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int yy = ty0 + 2 * wv + (n >> 1), xx = tx0 + (n & 1) * 16 + (lane & 15);
-            if (yy >= a.H || xx >= a.W) continue;
-            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[m][n][r] + bs[r];
-                if (a.relu) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (a.drop_p > 0.f) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= dropout_scale(a.seed, (unsigned)(p * a.COUT + c0 + r), a.drop_p, inv_keep);
-            }
-            bf16 *dst = o.y + p * o.C + cl;
-            if (o.relu_src) {
-                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o.relu_src + p * o.C + cl);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o.scale : 0.f;
-            }
-            if (o.accumulate) {
-                const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
-            }
-            bf16x4 outv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
-            *reinterpret_cast<bf16x4 *>(dst) = outv;
-        }
-    }
-}
-
-// Software-pipelined, persistent form of the same convolution: a block walks the stages
-// (tile, input-channel chunk) of its share of the tiles; while the matrix cores work on the
-// stage that sits in LDS, the next stage's halo tile (and weight block, when it changes) is
-// already in flight from HBM/L2 into registers and is written to LDS after the barrier.
-template <int CK, int CM>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_pipe_kernel(const ConvArgs a, int total_tiles)
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a, int total_tiles)
 {
     constexpr int NS = ksteps(CK);
     constexpr int MT = CM / 16;
@@ -420,33 +306,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_pipe_kernel(const ConvAr
     }
 }
 
-static int conv_variant()
-{
-    static const int v = [] { const char *e = getenv("MMK_CONV_VARIANT"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
 template <int CK, int CM>
 int launch_conv(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
-    if (smem > 64 * 1024)
+    static bool attr_set = false;   // per template instantiation
+    if (smem > 64 * 1024 && !attr_set) {
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int groups = (a.COUT + CM - 1) / CM;
-    if (conv_variant() == 0) {
-        hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(tiles, groups, a.B), dim3(CONV_THREADS), smem, st, a);
-    } else {
-        if (smem > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_pipe_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        // persistent grid: as many blocks as the LDS footprint lets a CU hold, on 256 CUs
-        int per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
-        per_cu = per_cu < 1 ? 1 : per_cu;
-        const int total = tiles * a.B;
-        int gx = (256 * per_cu * conv_variant()) / groups;
-        gx = gx < 1 ? 1 : (gx > total ? total : gx);
-        hipLaunchKernelGGL((conv3x3_pipe_kernel<CK, CM>), dim3(gx, groups), dim3(CONV_THREADS), smem, st, a, total);
-    }
+    // persistent grid: as many blocks as the LDS footprint lets a CU hold, on 256 CUs
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    const int total = tiles * a.B;
+    int gx = (256 * per_cu) / groups;
+    gx = gx < 1 ? 1 : (gx > total ? total : gx);
+    hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(gx, groups), dim3(CONV_THREADS), smem, st, a, total);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -688,8 +565,11 @@ template <int CK, int CM>
 int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(CM)) * sizeof(bf16);
-    if (smem > 64 * 1024)
+    static bool attr_set = false;   // per template instantiation
+    if (smem > 64 * 1024 && !attr_set) {
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
     const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
     // persistent grid sized to what the LDS footprint lets the 256 CUs hold: every extra block

@@ -271,6 +271,51 @@ def main():
                         seed_mask=np.int64(12), seed_fft=np.int64(13), seed_cfar=np.int64(14), pts=lpts,
                         lw_keys=np.array(list(lw_a.keys())), lw_a=np.array(list(lw_a.values())),
                         lw_b=np.array(list(lw_b.values())), **outs)
+    # ------------------------------------------------------------------ dataset-side tensor ops
+    # icp_weight_dataset.py needs pyboreas / vtr_pose_graph / vtr_utils / ROS to import; its
+    # augment_data and filter_map methods only use torch, so they are called unbound on a stand-in self.
+    for name in ("pyboreas", "pyboreas.utils", "pyboreas.utils.odometry", "pyboreas.utils.utils", "vtr_pose_graph",
+                 "vtr_pose_graph.graph_utils", "vtr_pose_graph.graph_iterators", "vtr_utils",
+                 "vtr_utils.bag_file_parsing", "utils", "utils.extract_graph"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["pyboreas.utils.odometry"].read_traj_file2 = None
+    sys.modules["pyboreas.utils.odometry"].read_traj_file_gt2 = None
+    for n in ("SE3Tose3", "get_closest_index", "get_inverse_tf", "rotToRollPitchYaw"):
+        setattr(sys.modules["pyboreas.utils.utils"], n, None)
+    sys.modules["vtr_utils.bag_file_parsing"].Rosbag2GraphFactory = None
+    sys.modules["vtr_pose_graph.graph_iterators"].TemporalIterator = None
+    sys.modules["utils.extract_graph"].extract_points_and_map = None
+    del sys.modules["icp_weight_dataset"]
+    import icp_weight_dataset as ds_mod
+    DS = ds_mod.ICPWeightDataset
+    me = types.SimpleNamespace(gt_eye=True, float_type=torch.float32, loc_sensor="radar", map_sensor="lidar")
+    rd = np.random.default_rng(21)
+    scan_raw = torch.from_numpy(rd.uniform(-60, 60, (40, 3)).astype(np.float32))
+    scan_filt = scan_raw.clone() + 0.01
+    map6 = torch.from_numpy(rd.uniform(-60, 60, (50, 6)).astype(np.float32))
+    az = torch.from_numpy(np.sort(rd.uniform(0, 2 * np.pi, 16)).astype(np.float32))
+    fft = torch.from_numpy(rd.uniform(0, 1, (16, 24)).astype(np.float32))
+    cf = (fft > 0.8).float()
+    torch.manual_seed(4321)
+    outs_aug = DS.augment_data(me, scan_raw.clone(), scan_filt.clone(), map6.clone(), az.clone(), fft.clone(), cf.clone())
+    torch.manual_seed(4321)
+    angle = (2 * np.pi * torch.rand(1, dtype=torch.float32)).item()
+    pts = torch.from_numpy(rd.uniform(-30, 30, (60, 3)).astype(np.float32))
+    pts[:, 2] = torch.from_numpy(rd.uniform(-2, 2, 60).astype(np.float32))
+    nrm = torch.from_numpy(rd.normal(size=(60, 3)).astype(np.float32))
+    nrm = nrm / nrm.norm(dim=1, keepdim=True)
+    Tgt = torch.eye(4)
+    Tgt[:2, :2] = torch.tensor([[np.cos(0.2), -np.sin(0.2)], [np.sin(0.2), np.cos(0.2)]])
+    Tgt[:3, 3] = torch.tensor([1.0, -2.0, 0.1])
+    fa_p, fa_n = DS.filter_map(me, pts, nrm, Tgt, return_aligned=True)
+    fb_p, fb_n = DS.filter_map(me, pts, nrm, Tgt, return_aligned=False)
+    np.savez_compressed(os.path.join(OUT, "dataset_ops.npz"), scan_raw=scan_raw.numpy(), scan_filt=scan_filt.numpy(),
+                        map6=map6.numpy(), az=az.numpy(), fft=fft.numpy(), cfar=cf.numpy(), angle=np.float64(angle),
+                        aug_raw=outs_aug[0].numpy(), aug_filt=outs_aug[1].numpy(), aug_map=outs_aug[2].numpy(),
+                        aug_az=outs_aug[3].numpy(), aug_fft=outs_aug[4].numpy(), aug_cfar=outs_aug[5].numpy(),
+                        pts=pts.numpy(), nrm=nrm.numpy(), T_gt=Tgt.numpy(), fa_p=fa_p.numpy(), fa_n=fa_n.numpy(),
+                        fb_p=fb_p.numpy(), fb_n=fb_n.numpy())
+
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
