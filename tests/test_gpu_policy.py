@@ -165,3 +165,27 @@ def test_training_reduces_loss_bf16():
     assert val.shape == (1, 3) and torch.isfinite(val).all()
     li, lo = trn.generate_baseline(model, [batch], baseline_type="val", device=DEV)
     assert lo < li
+
+
+def test_train_step_with_flat_grad_sync():
+    """The data-parallel hook on one GPU (world size 1): gradients produced by the HIP U-Net's
+    autograd.Function must land in the flat all-reduce bucket, and the step must match a plain one."""
+    from mm_masking_amd import ddp
+    raw, params, batch = _small_batch(B=2)
+    params = dict(params, dropout=0.0)
+    lw = trn.loss_weights_from(params)
+    torch.manual_seed(5)
+    m1 = LearnICPWeightPolicy(params).to(DEV)
+    m2 = LearnICPWeightPolicy(params).to(DEV)
+    m2.load_state_dict(m1.state_dict())
+    o1, o2 = trn.make_optimizer(m1, params), trn.make_optimizer(m2, params)
+    sync = ddp.FlatGradSync(m2)
+    m1.train(), m2.train()
+    for _ in range(2):
+        l1, _ = trn.train_step(m1, batch, o1, lw, DEV)
+        l2, _ = trn.train_step(m2, batch, o2, lw, DEV, grad_sync=sync)
+    assert abs(l1.item() - l2.item()) < 2e-2 * max(1.0, abs(l1.item()))
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    assert float(sync.flat.abs().sum()) > 0
+    d = max((a - b).abs().max().item() for a, b in zip(m1.state_dict().values(), m2.state_dict().values()))
+    assert d < 5e-4          # Adam steps of lr 1e-4; float-atomic summation order differs run to run
