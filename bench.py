@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="scan pairs per GPU per step (BASELINE configs[2])")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic batches kept resident in HBM")
+    ap.add_argument("--nn", choices=["brute", "grid"], default=None,
+                    help="nearest-neighbour engine of the dICP (default: the dICP config, 'brute' = north_star's kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -179,8 +181,11 @@ def main():
 
     from mm_masking_amd import _lib, ddp, synthetic
     from mm_masking_amd import train_icp_weights as trn
+    from mm_masking_amd.dICP.ICP import ICP
     from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
     L = _lib.lib()
+    if args.nn is not None:
+        ICP.NN_SEARCH_OVERRIDE = args.nn
 
     params = trn.default_params(device)
     params.update({"icp_type": "pt2pl", "icp_loss_fn": {"name": "huber", "metric": 1.0}, "icp_dim": DIM,
@@ -216,14 +221,22 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     fence()
+    import gc
+    gc.collect()
+    gc.freeze()      # keep the collector from re-scanning the long-lived objects inside the timed region
     progress("timing %d steps" % args.steps)
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(args.steps):
         loss, _ = one_step(args.warmup + i)
+        step_ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    progress("per-step GPU ms: " + " ".join("%.1f" % v for v in per_step))
     ms = (ctypes.c_float * cap)()
     n_rec = ctypes.c_int32(0)
     _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
@@ -258,7 +271,8 @@ def main():
                        "final_loss": float(loss)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nn_search_kernel<2>", "launches_timed": int(len(nn_ms)),
+                         "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else "nn_search_kernel<2,16,2>",
+                         "nn_engine": model.ICP_alg.nn_search, "launches_timed": int(len(nn_ms)),
                          "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "north_star names the HBM roofline; brute force does %.3g distance evaluations per "
                                  "launch over those bytes (~2.2 kFLOP/B), so the binding roofline is fp32 VALU" % evals,

@@ -38,6 +38,9 @@ extern "C" {
 #define MMK_ICP_PT2PT 0
 #define MMK_ICP_PT2PL 1
 
+#define MMK_NN_BRUTE 0 /* exhaustive scan (north_star's brute-force kernel)                  */
+#define MMK_NN_GRID 1  /* exact search through a uniform grid: same indices, fewer evaluations */
+
 #define MMK_LOSS_NONE 0
 #define MMK_LOSS_CAUCHY 1
 #define MMK_LOSS_HUBER 2
@@ -66,6 +69,7 @@ typedef struct {
     int32_t check_every;/* >0: every that many iterations read the active flags
                            back (synchronises `stream`) and stop when all pairs
                            froze; 0: run max_iter iterations, never synchronise   */
+    int32_t nn_method;  /* MMK_NN_BRUTE | MMK_NN_GRID: both return identical indices     */
 } mmk_icp_params;
 
 size_t mmk_icp_workspace_bytes(const mmk_icp_params *p);

@@ -36,7 +36,7 @@ class IcpParams(ctypes.Structure):
                 ("tgt_cols", ctypes.c_int32), ("dim", ctypes.c_int32), ("icp_type", ctypes.c_int32),
                 ("loss", ctypes.c_int32), ("loss_k", ctypes.c_float), ("trim_dist", ctypes.c_float),
                 ("tolerance", ctypes.c_float), ("max_iter", ctypes.c_int32), ("save_state", ctypes.c_int32),
-                ("check_every", ctypes.c_int32)]
+                ("check_every", ctypes.c_int32), ("nn_method", ctypes.c_int32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -53,6 +53,7 @@ class ConvDesc(ctypes.Structure):
 
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
 LOSSES = {None: 0, "none": 0, "l2": 0, "cauchy": 1, "huber": 2}
+NN_METHODS = {"brute": 0, "grid": 1}
 
 
 def build(verbose=False):

@@ -210,6 +210,167 @@ __global__ void nn_unpack_kernel(const unsigned long long *__restrict__ packed, 
     d2[i] = __uint_as_float((unsigned)(key >> 32));
 }
 
+
+// ------------------------------------------------------------------------------------------
+// I2, accelerated form: EXACT nearest neighbour through a uniform 2-D grid
+// over the target's x,y.  It returns bit for bit what the brute-force scan returns — the same
+// nn_dist() arithmetic on the same coordinates, ties to the lowest original index — but only
+// visits the cells that can hold the answer: rings of cells around the query are scanned until
+// the best distance is provably smaller than anything an unvisited ring can offer (a point in a
+// cell at Chebyshev ring r+1 is at least r cells away; targets/queries outside the grid are
+// clamped to the border cells, which only makes them farther than the bound).  A query that is
+// still unresolved after GRID_RMAX rings scans every target.  The grid is built once per icp()
+// call (the target does not move between iterations).
+constexpr int GRID_N = 128;
+constexpr int GRID_NC = GRID_N * GRID_N;
+constexpr float GRID_CELL = 2.0f;
+constexpr float GRID_ORG = -128.0f;
+constexpr int GRID_RMAX = 24;
+
+__device__ __forceinline__ int grid_coord(float v)
+{
+    const float f = floorf((v - GRID_ORG) / GRID_CELL);
+    return (int)fminf(fmaxf(f, 0.f), (float)(GRID_N - 1));
+}
+
+__global__ void grid_count_kernel(const float *__restrict__ tgt, int M, int cols, int32_t *__restrict__ counts)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= M) return;
+    const float *t = tgt + ((size_t)b * M + j) * cols;
+    const int cell = grid_coord(t[1]) * GRID_N + grid_coord(t[0]);
+    atomicAdd(&counts[(size_t)b * GRID_NC + cell], 1);
+}
+
+__global__ __launch_bounds__(256) void grid_scan_kernel(const int32_t *__restrict__ counts, int32_t *__restrict__ starts)
+{
+    __shared__ int sm[4];
+    const int b = blockIdx.x;
+    constexpr int L = GRID_NC / 256;
+    const int32_t *c = counts + (size_t)b * GRID_NC + threadIdx.x * L;
+    int s = 0;
+    for (int i = 0; i < L; ++i) s += c[i];
+    // block exclusive scan of 256 partial sums
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sm[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += sm[w];
+    int run = base + inc - s;
+    int32_t *o = starts + (size_t)b * (GRID_NC + 1) + threadIdx.x * L;
+    for (int i = 0; i < L; ++i) {
+        o[i] = run;
+        run += c[i];
+    }
+    if (threadIdx.x == 255) starts[(size_t)b * (GRID_NC + 1) + GRID_NC] = run;
+}
+
+__global__ void grid_fill_kernel(const float *__restrict__ tgt, int M, int cols, int dim, const int32_t *__restrict__ starts,
+                                 int32_t *__restrict__ cursor, float4 *__restrict__ sorted)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= M) return;
+    const float *t = tgt + ((size_t)b * M + j) * cols;
+    const int cell = grid_coord(t[1]) * GRID_N + grid_coord(t[0]);
+    const int pos = starts[(size_t)b * (GRID_NC + 1) + cell] + atomicAdd(&cursor[(size_t)b * GRID_NC + cell], 1);
+    sorted[(size_t)b * M + pos] = make_float4(t[0], t[1], dim == 3 ? t[2] : 0.f, __int_as_float(j));
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void grid_nn_kernel(const float *__restrict__ src, const float *__restrict__ Tk,
+                                                      const int32_t *__restrict__ active,
+                                                      const int32_t *__restrict__ starts,
+                                                      const float4 *__restrict__ sorted, int N, int M,
+                                                      const float *__restrict__ tgt, int cols,
+                                                      const int32_t *__restrict__ prev_idx,
+                                                      unsigned long long *__restrict__ packed)
+{
+    const int b = blockIdx.y;
+    if (active != nullptr && active[b] == 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float T[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[q] = Tk[(size_t)b * 16 + q];
+    const float *sp = src + ((size_t)b * N + i) * 3;
+    const float s[3] = {sp[0], sp[1], sp[2]};
+    float p[DIM];
+    transform_point<DIM>(T, s, p);
+    const int cx = grid_coord(p[0]), cy = grid_coord(p[1]);
+    const int32_t *st = starts + (size_t)b * (GRID_NC + 1);
+    const float4 *pts = sorted + (size_t)b * M;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+
+    // candidates are fetched eight at a time (independent 16-byte loads) before they are compared:
+    // the search is latency-bound, not ALU-bound
+    auto scan = [&](int k0, int k1) {
+        for (int k = k0; k < k1; k += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pts[min(k + u, k1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = nn_dist<DIM>(t[u].x, t[u].y, t[u].z, p);
+                const int j = __float_as_int(t[u].w);
+                if (d < best || (d == best && j < bi)) {
+                    best = d;
+                    bi = j;
+                }
+            }
+        }
+    };
+
+    auto scan_square = [&](int r) {
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, GRID_N - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, GRID_N - 1);
+        int k0 = st[y0 * GRID_N + x0], k1 = st[y0 * GRID_N + x1 + 1];
+        for (int y = y0; y <= y1; ++y) {
+            const int yn = min(y + 1, y1);
+            const int n0 = st[yn * GRID_N + x0], n1 = st[yn * GRID_N + x1 + 1];   // next row's range in flight
+            scan(k0, k1);
+            k0 = n0;
+            k1 = n1;
+        }
+    };
+
+    bool done = false;
+    if (prev_idx != nullptr) {
+        // the previous iteration's correspondent bounds the search: every target at most that far
+        // away (the answer and all its ties) lies within r cells of the query's cell
+        const float *tp = tgt + ((size_t)b * M + prev_idx[(size_t)b * N + i]) * cols;
+        const float u = nn_dist<DIM>(tp[0], tp[1], DIM == 3 ? tp[2] : 0.f, p);
+        const int r = (int)floorf((sqrtf(u) + 1e-3f) / GRID_CELL) + 1;
+        if (r <= GRID_RMAX) {
+            scan_square(r);
+            done = true;
+        }
+    }
+    // growing squares of cells around the query (inner cells are simply seen again: harmless);
+    // after the square of radius r everything unvisited is at least r cells away
+    const int radii[8] = {1, 2, 3, 5, 8, 12, 17, GRID_RMAX};
+    for (int ri = 0; ri < 8 && !done; ++ri) {
+        const int r = radii[ri];
+        scan_square(r);
+        const float lim = (float)r * GRID_CELL - 1e-3f;   // 1 mm of slack for the float cell assignment
+        done = best < lim * lim;
+    }
+    if (!done) {   // far from every target: exhaustive scan (still exact)
+        best = INFINITY;
+        bi = 0x7fffffff;
+        scan(0, M);
+    }
+    packed[(size_t)b * N + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(unsigned)bi;
+}
+
 // ------------------------------------------------------------------------------------------
 // I3 + I4 per-point terms (oracle: per_point_terms).
 template <int DIM, int TYPE>
@@ -868,6 +1029,7 @@ int check_params(const mmk_icp_params *p)
     MMK_REQUIRE(p->loss >= MMK_LOSS_NONE && p->loss <= MMK_LOSS_HUBER, "mmk_icp: bad loss %d", p->loss);
     MMK_REQUIRE(p->max_iter >= 1, "mmk_icp: max_iter must be >= 1");
     MMK_REQUIRE(p->loss == MMK_LOSS_NONE || p->loss_k > 0.f, "mmk_icp: loss metric must be > 0");
+    MMK_REQUIRE(p->nn_method == MMK_NN_BRUTE || p->nn_method == MMK_NN_GRID, "mmk_icp: bad nn_method %d", p->nn_method);
     return MMK_OK;
 }
 
@@ -878,6 +1040,8 @@ struct IcpWs {
     double *G0, *G1;    // backward (B,16)
     double *lam;        // backward (B,6)
     int32_t *host_flag_dev;
+    int32_t *g_counts, *g_cursor, *g_starts;  // grid NN: (B,NC), (B,NC), (B,NC+1)
+    float4 *g_sorted;                          // grid NN: (B,M) x,y,z,index
     size_t bytes;
 };
 
@@ -894,6 +1058,14 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     w.G1 = ar.take<double>((size_t)p->B * 16);
     w.lam = ar.take<double>((size_t)p->B * 6);
     w.host_flag_dev = ar.take<int32_t>(16);
+    w.g_counts = w.g_cursor = w.g_starts = nullptr;
+    w.g_sorted = nullptr;
+    if (p->nn_method == MMK_NN_GRID) {
+        w.g_counts = ar.take<int32_t>((size_t)p->B * GRID_NC * 2);
+        w.g_cursor = w.g_counts + (size_t)p->B * GRID_NC;
+        w.g_starts = ar.take<int32_t>((size_t)p->B * (GRID_NC + 1));
+        w.g_sorted = ar.take<float4>((size_t)p->B * p->M);
+    }
     w.bytes = mmk::align_up(ar.off, 256);
     return w;
 }
@@ -909,12 +1081,37 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
     MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
+    const bool use_grid = p->nn_method == MMK_NN_GRID;
+    if (use_grid) {   // the target is fixed over the iterations: bin it once
+        MMK_CHECK_HIP(hipMemsetAsync(w.g_counts, 0, sizeof(int32_t) * (size_t)B * GRID_NC * 2, st));
+        hipLaunchKernelGGL(grid_count_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, tgt, M, p->tgt_cols, w.g_counts);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_scan_kernel, dim3(B), dim3(256), 0, st, w.g_counts, w.g_starts);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_fill_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, tgt, M, p->tgt_cols, DIM, w.g_starts,
+                           w.g_cursor, w.g_sorted);
+        MMK_LAUNCH_CHECK();
+    }
     for (int it = 0; it < p->max_iter; ++it) {
         const float *Tk = T_hist + (size_t)it * B * 16;
         const int32_t *act = active_hist + (size_t)it * B;
         int32_t *idx = idx_hist + (p->save_state ? (size_t)it * B * N : 0);
-        int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.packed, st);
-        if (rc != MMK_OK) return rc;
+        if (use_grid) {
+            const bool rec = g_prof.on && g_prof.n < g_prof.cap;
+            if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+            // the correspondences of the previous iteration (still in the index buffer) bound the search
+            const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
+            hipLaunchKernelGGL(grid_nn_kernel<DIM>, dim3((N + 255) / 256, B), dim3(256), 0, st, src, Tk, act, w.g_starts,
+                               w.g_sorted, N, M, tgt, p->tgt_cols, prev, w.packed);
+            MMK_LAUNCH_CHECK();
+            if (rec) {
+                MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+                g_prof.n++;
+            }
+        } else {
+            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.packed, st);
+            if (rc != MMK_OK) return rc;
+        }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
                            p->tgt_cols, weight, Tk, act, w.packed, idx, N, M, p->loss, k, k2, trim2, w.partials);
         MMK_LAUNCH_CHECK();

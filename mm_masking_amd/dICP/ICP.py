@@ -93,6 +93,8 @@ class _IcpFunction(torch.autograd.Function):
 
 
 class ICP:
+    NN_SEARCH_OVERRIDE = None      # tests / benchmarks: force "brute" or "grid" for every instance
+
     def __init__(self, icp_type="pt2pl", config_path=None, differentiable=True, max_iterations=100, tolerance=1e-12):
         if icp_type not in _lib.ICP_TYPES:
             raise ValueError("icp_type must be 'pt2pt' or 'pt2pl' (got %r)" % (icp_type,))
@@ -111,6 +113,11 @@ class ICP:
         self.config_path = config_path
         self.target_pad_val = float(cfg.get("target_pad_val", 1000.0))
         self.check_every = int((cfg.get("parameters") or {}).get("check_every", 8))
+        # "brute": the exhaustive LDS-tiled scan; "grid": exact search through a uniform grid
+        # (identical correspondences, ~100x fewer distance evaluations)
+        self.nn_search = ICP.NN_SEARCH_OVERRIDE or str((cfg.get("parameters") or {}).get("nn_search", "brute"))
+        if self.nn_search not in _lib.NN_METHODS:
+            raise ValueError("dICP config: nn_search must be 'brute' or 'grid' (got %r)" % (self.nn_search,))
         self.last_state = None
         self.last_iterations = None
 
@@ -122,7 +129,8 @@ class ICP:
                               loss=_lib.LOSSES[name], loss_k=float(1.0 if loss_fn is None else loss_fn.get("metric", 1.0)),
                               trim_dist=float(trim_dist), tolerance=self.tolerance, max_iter=self.max_iterations,
                               save_state=1 if save_state else 0,
-                              check_every=0 if save_state else self.check_every)
+                              check_every=0 if save_state else self.check_every,
+                              nn_method=_lib.NN_METHODS[self.nn_search])
 
     def icp(self, source, target, T_init=None, weight=None, trim_dist=5.0, loss_fn=None, dim=3):
         if source.ndim != 3 or source.shape[-1] != 3:

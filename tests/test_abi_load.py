@@ -32,17 +32,21 @@ def test_header_symbols_exported(L):
 
 def test_host_side_argument_checks(L):
     p = _lib.IcpParams(B=2, N=100, M=300, tgt_cols=6, dim=2, icp_type=1, loss=2, loss_k=1.0, trim_dist=5.0,
-                       tolerance=1e-5, max_iter=10, save_state=1, check_every=0)
+                       tolerance=1e-5, max_iter=10, save_state=1, check_every=0, nn_method=0)
     need = L.mmk_icp_workspace_bytes(ctypes.byref(p))
     assert need > 2 * 2 * 1024 * 4
     assert L.mmk_nn_padded_m(20000) == 20480 and L.mmk_nn_padded_m(1) == 1024
     assert L.mmk_nn_workspace_bytes(32, 5120, 20000, 2) >= 2 * 32 * 5120 * 4
     bad = _lib.IcpParams(B=2, N=100, M=300, tgt_cols=3, dim=2, icp_type=1, loss=2, loss_k=1.0, trim_dist=5.0,
-                         tolerance=1e-5, max_iter=10, save_state=1, check_every=0)
+                         tolerance=1e-5, max_iter=10, save_state=1, check_every=0, nn_method=0)
     assert L.mmk_icp_workspace_bytes(ctypes.byref(bad)) == 0
     assert b"normals" in L.mmk_last_error()
     bad.tgt_cols, bad.dim = 6, 4
     assert L.mmk_icp_workspace_bytes(ctypes.byref(bad)) == 0 and b"dim" in L.mmk_last_error()
+    bad.dim, bad.nn_method = 2, 7
+    assert L.mmk_icp_workspace_bytes(ctypes.byref(bad)) == 0 and b"nn_method" in L.mmk_last_error()
+    p.nn_method = 1
+    assert L.mmk_icp_workspace_bytes(ctypes.byref(p)) > need      # the grid engine carves its cell tables
     null = ctypes.c_void_p(0)
     assert L.mmk_cfar_mask(null, 1, 1, 1, 50, 5, 56, 1, 1.0, 0.09, 0, 10.0, null, null) == -1
     assert L.mmk_nn_search(null, null, null, 1, 1, 1, 2, null, null, null, 0, null) == -1

@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
+@pytest.fixture(params=["brute", "grid"], autouse=True)
+def nn_engine(request):
+    """Every ICP test runs with both nearest-neighbour engines: the exhaustive scan and the exact
+    uniform-grid search must produce identical correspondences."""
+    ICP.NN_SEARCH_OVERRIDE = request.param
+    yield request.param
+    ICP.NN_SEARCH_OVERRIDE = None
+
+
 def _nn_gpu(src, tgt, T, dim):
     L = _lib.lib()
     B, N, _ = src.shape
@@ -208,6 +217,35 @@ def test_icp_tolerance_freezes_pairs_and_early_exit():
     assert np.abs(T.cpu().numpy()[0, :2, 3] - T_true[0, :2, 3]).max() < 0.05
 
 
+def test_grid_nn_far_queries_and_clamped_targets():
+    """Grid engine corner cases: queries far outside the grid / far from every target (exhaustive
+    fallback), targets outside the grid (clamped to border cells), exact duplicates (lowest index)."""
+    rng = np.random.default_rng(3)
+    B, N, M = 2, 600, 3000
+    tgt = np.zeros((B, M, 6), np.float32)
+    tgt[:, :, :2] = rng.uniform(-60, 60, (B, M, 2))
+    tgt[:, :50, :2] = rng.uniform(150, 400, (B, 50, 2))          # beyond the 256 m grid
+    tgt[:, 2900:, :] = 1000.0                                    # target_pad_val rows
+    tgt[:, 100, :2] = tgt[:, 7, :2]                              # duplicate point
+    src = np.zeros((B, N, 3), np.float32)
+    src[:, :, :2] = rng.uniform(-70, 70, (B, N, 2))
+    src[:, :40, :2] = rng.uniform(200, 500, (B, 40, 2))          # far queries
+    src[:, 40:60, :2] = rng.uniform(-500, -130, (B, 20, 2))
+    src[:, 60, :2] = tgt[:, 7, :2]
+    T0 = torch.eye(4).repeat(B, 1, 1)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "cauchy", "metric": 1.0}, dim=2)
+    ref = dicp_ref.ICPRef("pt2pt", differentiable=False, max_iterations=2, tolerance=1e-9)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=T0, **kw)
+    icp = ICP("pt2pt", differentiable=True, max_iterations=2, tolerance=1e-9)
+    w = torch.ones(B, N, device=DEV, requires_grad=True)
+    T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=T0.to(DEV), weight=w, **kw)["T"]
+    idx = T.grad_fn.saved_tensors[3].cpu().numpy()
+    for k in range(2):
+        np.testing.assert_array_equal(idx[k], out["hist"]["idx"][k].numpy())
+    assert idx[0][0, 60] == 7
+    np.testing.assert_allclose(T.detach().cpu().numpy(), out["T"].numpy(), atol=2e-6)
+
+
 def test_icp_error_behaviour():
     icp = ICP("pt2pl", differentiable=False, max_iterations=2)
     s = torch.zeros(1, 8, 3, device=DEV)
@@ -218,7 +256,7 @@ def test_icp_error_behaviour():
     with pytest.raises(ValueError):
         icp.icp(s, torch.zeros(1, 8, 6, device=DEV), dim=4)
     p = _lib.IcpParams(B=1, N=8, M=8, tgt_cols=6, dim=2, icp_type=1, loss=2, loss_k=1.0, trim_dist=5.0, tolerance=0.0,
-                       max_iter=2, save_state=0, check_every=0)
+                       max_iter=2, save_state=0, check_every=0, nn_method=0)
     L = _lib.lib()
     rc = L.mmk_icp_forward(ctypes.byref(p), *([ctypes.c_void_p(8)] * 10), ctypes.c_void_p(0), 0, None, ctypes.c_void_p(0))
     assert rc == -3 and b"workspace" in L.mmk_last_error()
