@@ -233,10 +233,12 @@ def main():
     for i in range(args.steps):
         loss, _ = one_step(args.warmup + i)
         step_ev[i + 1].record()
+    host_dt = time.perf_counter() - t0        # host-side enqueue time (the GPU may still be running)
     fence()
     dt = time.perf_counter() - t0
     per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     progress("per-step GPU ms: " + " ".join("%.1f" % v for v in per_step))
+    progress("host enqueue time %.1f ms/step" % (host_dt / args.steps * 1e3))
     ms = (ctypes.c_float * cap)()
     n_rec = ctypes.c_int32(0)
     _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
