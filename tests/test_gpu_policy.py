@@ -189,3 +189,42 @@ def test_train_step_with_flat_grad_sync():
     assert float(sync.flat.abs().sum()) > 0
     d = max((a - b).abs().max().item() for a, b in zip(m1.state_dict().values(), m2.state_dict().values()))
     assert d < 5e-4          # Adam steps of lr 1e-4; float-atomic summation order differs run to run
+
+
+def test_hip_unet_with_cfar_and_range_inputs():
+    """3-channel network input (fft | cfar | range, icp_weight_policy.py:139-147): the first-layer
+    kernel and its weight gradient with cin = 3, inside the whole network, vs the fp32 module."""
+    over = {"cfar_input": True, "range_input": True, "normalize": ["standardize"]}
+    torch.manual_seed(21)
+    mh = LearnICPWeightPolicy(_params(**over)).to(DEV)
+    mt = LearnICPWeightPolicy(_params(amp_dtype=torch.float32, unet_backend="torch", **over)).to(DEV)
+    mt.load_state_dict(mh.state_dict())
+    H = 96
+    mh.range_mask = mh.range_mask[:H, :H].contiguous()
+    mt.range_mask = mt.range_mask[:H, :H].contiguous()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, H, H, generator=g)
+    c = (torch.rand(2, H, H, generator=g) > 0.9).float()
+    scan = {"fft_data": x, "fft_cfar": c, "raw_pc": torch.zeros(2, 4, 3)}
+    mh.train(), mt.train()
+    a = mh(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    b = mt(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    assert (a - b).abs().max().item() < 5e-3
+    gsel = torch.randn(2, H, H, generator=g).to(DEV)
+    (a * gsel).sum().backward()
+    (b * gsel).sum().backward()
+    ga, gb = mh.encoder[0][0].weight.grad, mt.encoder[0][0].weight.grad
+    assert ga.shape == (8, 3, 3, 3)
+    assert torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item() > 0.9
+
+
+def test_polar_network_input_runs_on_module_path():
+    """network_input_type='polar' (icp_weight_policy.py:61-62): 400x3360-like odd pooling sizes are
+    outside the hand-written kernels' shape contract and run the nn.Module path."""
+    p = _params(network_input_type="polar", network_output_type="polar")
+    torch.manual_seed(2)
+    m = LearnICPWeightPolicy(p).to(DEV)
+    assert tuple(m.range_mask.shape) == (400, 3360)
+    x = torch.rand(1, 100, 168)
+    out = m({"fft_data": x, "fft_cfar": x, "raw_pc": torch.zeros(1, 4, 3)}, {"pc": torch.zeros(1, 4, 6)}, None, mask_only=True)
+    assert out.shape == (1, 100, 168) and torch.isfinite(out).all()
