@@ -66,8 +66,9 @@ def nn_algorithmic_bytes(B):
 
 
 def cpu_baseline(params_like, sample_pairs=4, timed_steps=3):
-    """The oracle's PyTorch-CPU port of the same train step (oracle/train_ref.py) on a
-    bounded sample: `sample_pairs` pairs per step, 1 warm-up + `timed_steps` steps."""
+    """The cpu_baseline leg — the only part of bench.py that touches oracle/: the oracle's
+    PyTorch-CPU port of the same train step (oracle/train_ref.py) timed on a bounded sample
+    (`sample_pairs` pairs per step, 1 warm-up + `timed_steps` steps)."""
     from mm_masking_amd import synthetic
     from oracle import radar_ref, train_ref
     torch.set_num_threads(usable_cores())
@@ -125,7 +126,8 @@ def conv_stack_rate(model, raw, params, device, reps=3):
 
 
 def pose_parity(model, params, device, pairs=2):
-    """GPU dICP vs the CPU restatement on identical inputs (outside the timed region)."""
+    """Part of the cpu_baseline leg: GPU dICP vs the CPU restatement on identical inputs
+    (the oracle as checker, outside the timed region)."""
     from mm_masking_amd import synthetic
     from mm_masking_amd import train_icp_weights as trn
     from mm_masking_amd.dICP.ICP import ICP
@@ -173,11 +175,16 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP kernels with no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" = RCCL over xGMI; MMK_BENCH_BACKEND=gloo only for rehearsing the rank logic on a 1-GPU box
+        backend = os.environ.get("MMK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mm_masking_amd import _lib, ddp, synthetic
     from mm_masking_amd import train_icp_weights as trn
@@ -285,11 +292,11 @@ def main():
         }
         if world == 1:
             result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)
-        if world == 1 and not args.no_parity:
-            progress("pose parity vs the CPU restatement")
-            result["pose_parity_vs_cpu_restatement"] = pose_parity(model, params, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(params)
+            if not args.no_parity:
+                progress("cpu_baseline: pose parity of the GPU dICP vs the CPU restatement")
+                result["cpu_baseline"]["pose_parity"] = pose_parity(model, params, device)
         print(json.dumps(result))
         sys.stdout.flush()
     if world > 1:
