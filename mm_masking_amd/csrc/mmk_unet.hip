@@ -310,10 +310,14 @@ template <int CK, int CM>
 int launch_conv(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
-    static bool attr_set = false;   // per template instantiation
-    if (smem > 64 * 1024 && !attr_set) {
-        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+    if (smem > 64 * 1024) {
+        static bool attr_set[64] = {};   // per template instantiation and device
+        int dev = 0;
+        MMK_CHECK_HIP(hipGetDevice(&dev));
+        if (!attr_set[dev & 63]) {
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set[dev & 63] = true;
+        }
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int groups = (a.COUT + CM - 1) / CM;
@@ -565,10 +569,14 @@ template <int CK, int CM>
 int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(CM)) * sizeof(bf16);
-    static bool attr_set = false;   // per template instantiation
-    if (smem > 64 * 1024 && !attr_set) {
-        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+    if (smem > 64 * 1024) {
+        static bool attr_set[64] = {};   // per template instantiation and device
+        int dev = 0;
+        MMK_CHECK_HIP(hipGetDevice(&dev));
+        if (!attr_set[dev & 63]) {
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set[dev & 63] = true;
+        }
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
     const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
