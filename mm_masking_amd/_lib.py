@@ -61,7 +61,8 @@ def build(verbose=False):
     (hipcc cross-compiles without a GPU).  -ffp-contract=off is part of the
     numerical contract."""
     srcs = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(_HERE, "csrc", "mmk_common.h"), os.path.join(_ROOT, "include", "mmk.h")]
+    deps = srcs + [os.path.join(_HERE, "csrc", "mmk_common.h"), os.path.join(_HERE, "csrc", "mmk_conv_ring_stage.inc"),
+                   os.path.join(_ROOT, "include", "mmk.h")]
     if os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

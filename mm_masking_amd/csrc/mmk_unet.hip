@@ -254,7 +254,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
                 const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
                 if (c0 < a.COUT) {
                     const bool firstp = c0 < a.o1.C;
-                    const ConvOutPart &o = firstp ? a.o1 : a.o2;
+                    bf16 *o_y = firstp ? a.o1.y : a.o2.y;
+                    const bf16 *o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
+                    const int o_C = firstp ? a.o1.C : a.o2.C;
+                    const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
+                    const float o_scale = firstp ? a.o1.scale : a.o2.scale;
                     const int cl = firstp ? c0 : c0 - a.o1.C;
                     float bs[4] = {0.f, 0.f, 0.f, 0.f};
                     if (a.bias) {
@@ -277,13 +281,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
                                 for (int r = 0; r < 4; ++r)
                                     v[r] *= dropout_scale(a.seed, (unsigned)(p * a.COUT + c0 + r), a.drop_p, inv_keep);
                             }
-                            bf16 *dst = o.y + p * o.C + cl;
-                            if (o.relu_src) {
-                                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o.relu_src + p * o.C + cl);
+                            bf16 *dst = o_y + p * o_C + cl;
+                            if (o_src) {
+                                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o_src + p * o_C + cl);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o.scale : 0.f;
+                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f;
                             }
-                            if (o.accumulate) {
+                            if (o_acc) {
                                 const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
@@ -332,9 +336,216 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
     return MMK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Streaming variant for the layers whose input channels fit one chunk (CIN = CK <= 32): the
+// 640x640 / 320x320 levels, which are bound by HBM latency x bytes in flight, not by the
+// matrix cores.  Differences from conv3x3_kernel:
+//   * a ring of RD register slots keeps RD halo tiles in flight per block (one slot is
+//     written to LDS per stage and re-armed at once), LDS is double buffered -> one barrier
+//     per stage, and that barrier only waits for LDS (lgkmcnt), never for the loads in flight;
+//   * every global load is unconditional (out-of-image granules read a 16-byte zero word), so
+//     the compiler's vmcnt bookkeeping stays exact and a wait for tile k+1 does not drain the
+//     loads of tiles k+2..k+RD;
+//   * the epilogue's operands (ReLU-backward source, accumulate target) are fetched at the top
+//     of the stage, behind nothing, and are consumed after the MFMA loop (EPI = true);
+//   * each XCD walks its own contiguous range of tiles, so halo rows shared by neighbouring
+//     tiles hit that XCD's L2.
+// native vector type: the HIP uint4 struct is copied by memcpy, which keeps a register ring in scratch
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ u32x4 g_zero16;   // zero-initialised, never written
+__device__ u32x4 g_sink16[4]; // write-only: where lanes without an output element store
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int CK, int CM, int RD, bool EPI>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
+{
+    constexpr int NS = ksteps(CK);
+    constexpr int MT = CM / 16;
+    constexpr int NT = 4;
+    constexpr int PK = lds_pitch(CK);
+    constexpr int GPP = CK / 8;
+    constexpr int NIN = HT * WT * GPP;
+    constexpr int NW = NS * MT * 64;
+    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
+    bf16 *w_lds = in_tile + 2 * HT * WT * PK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int group = blockIdx.y;
+
+    const int xcd = blockIdx.x & 7, nb = gridDim.x >> 3;
+    const int t_begin = xcd * tiles_per_xcd;
+    const int t_end = (t_begin + tiles_per_xcd < total_tiles) ? t_begin + tiles_per_xcd : total_tiles;
+    const int first = t_begin + (blockIdx.x >> 3);
+    if (first >= t_end) return;
+    const int nt_blk = (t_end - first + nb - 1) / nb;         // tiles of this block: first + k * nb
+
+    u32x4 rin[RD][RIN];
+    // the granules this thread stages are the same for every tile: precompute their place in the tile
+    int g_dy[RIN], g_dx[RIN], g_c[RIN];
+#pragma unroll
+    for (int i = 0; i < RIN; ++i) {
+        int g = tid + i * CONV_THREADS;
+        g = g < NIN ? g : NIN - 1;
+        const int pix = g / GPP;
+        g_dy[i] = pix / WT - 1;
+        g_dx[i] = pix % WT - 1;
+        g_c[i] = (g % GPP) * 8;
+    }
+
+#define MMK_RING_LOAD(SLOT, KK)                                                                              \
+    {                                                                                                        \
+        int kk_ = (KK);                                                                                      \
+        kk_ = kk_ < nt_blk ? kk_ : nt_blk - 1;                                                               \
+        const int t_ = first + kk_ * nb;                                                                     \
+        const int b_ = t_ / tpi, tr_ = t_ - b_ * tpi;                                                        \
+        const int ty_ = tr_ / tiles_x;                                                                       \
+        const int tx0_ = (tr_ - ty_ * tiles_x) * TW, ty0_ = ty_ * TH;                                        \
+        _Pragma("unroll") for (int i = 0; i < RIN; ++i) {                                                    \
+            const int yy = ty0_ + g_dy[i], xx = tx0_ + g_dx[i];                                              \
+            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;                                      \
+            const size_t p_ = ((size_t)b_ * a.H + yy) * a.W + xx;                                            \
+            const bf16 *src = (g_c[i] < a.C1) ? a.x1 + p_ * a.C1 + g_c[i] : a.x2 + p_ * a.C2 + (g_c[i] - a.C1); \
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16;                         \
+            rin[SLOT][i] = *sp;                                                                              \
+        }                                                                                                    \
+    }
+#define MMK_RING_STORE(SLOT, BUF)                                                                            \
+    {                                                                                                        \
+        bf16 *dst_ = in_tile + (BUF) * (HT * WT * PK);                                                       \
+        _Pragma("unroll") for (int i = 0; i < RIN; ++i) {                                                    \
+            const int g = tid + i * CONV_THREADS;                                                            \
+            if (g < NIN) *reinterpret_cast<u32x4 *>(dst_ + (size_t)(g / GPP) * PK + (g % GPP) * 8) = rin[SLOT][i]; \
+        }                                                                                                    \
+    }
+
+    // weights: one block of NS x MT fragments, resident for the whole kernel
+    {
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + (size_t)group * NS * MT * 512);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * CONV_THREADS;
+            if (g < NW) reinterpret_cast<u32x4 *>(w_lds)[g] = wsrc[g];
+        }
+    }
+    MMK_RING_LOAD(0, 0);
+    MMK_RING_LOAD(1, 1);
+    if constexpr (RD > 2) MMK_RING_LOAD(2, 2);
+    MMK_RING_STORE(0, 0);
+    MMK_RING_LOAD(0, RD);
+    // as many (sink) stores as one epilogue issues: the first stage then enters with the same
+    // load/store queue shape as every later one, and its vmcnt wait is the steady-state one
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i) reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull;
+
+    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    // per-lane output channel bookkeeping (does not depend on the tile)
+    float bs[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
+        const float *bp = (a.bias && c0 < a.COUT) ? a.bias + c0 : reinterpret_cast<const float *>(&g_zero16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[m][r] = bp[r];
+    }
+
+    // The first round is peeled off the loop: hipcc merges the load/store queue state of every edge
+    // into the loop header by its minimum, and the prologue's short queue would otherwise turn the
+    // header's wait for tile k+1 into a drain of the whole ring on every round.
+    int k0 = 0;
+    {
+#define STAGE_SLOT 0
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+#define STAGE_SLOT 1
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        if constexpr (RD > 2) {
+#define STAGE_SLOT 2
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        }
+    }
+    for (k0 = RD;; k0 += RD) {
+#define STAGE_SLOT 0
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+#define STAGE_SLOT 1
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        if constexpr (RD > 2) {
+#define STAGE_SLOT 2
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        }
+    }
+ring_done:;
+#undef MMK_RING_LOAD
+#undef MMK_RING_STORE
+}
+
+template <int CK, int CM, int RD, bool EPI>
+int launch_conv_ring(const ConvArgs &a, hipStream_t st)
+{
+    const size_t smem = ((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
+    static int per_cu[64] = {};     // resident blocks per CU (registers / LDS), per device
+    int dev = 0;
+    MMK_CHECK_HIP(hipGetDevice(&dev));
+    if (per_cu[dev & 63] == 0) {
+        if (smem > 64 * 1024)
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_ring_kernel<CK, CM, RD, EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nblk = 0;
+        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_ring_kernel<CK, CM, RD, EPI>, CONV_THREADS, smem));
+        per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
+    }
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int groups = (a.COUT + CM - 1) / CM;
+    const int total = tiles * a.B;
+    const int per_xcd = (total + 7) / 8;
+    int nb = (32 * per_cu[dev & 63]) / groups;                 // blocks per XCD (32 CUs each)
+    nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
+    hipLaunchKernelGGL((conv3x3_ring_kernel<CK, CM, RD, EPI>), dim3(8 * nb, groups), dim3(CONV_THREADS), smem, st, a, total, per_xcd);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+template <int CK, int CM>
+int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
+{
+    constexpr int RD = CK <= 16 ? 3 : 2;
+    const bool epi = a.o1.relu_src || a.o1.accumulate || (a.o2.C > 0 && (a.o2.relu_src || a.o2.accumulate));
+    return epi ? launch_conv_ring<CK, CM, RD, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
+}
+
+bool use_ring_kernels()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_CONV_RING");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int dispatch_conv(const ConvArgs &a, hipStream_t st)
 {
     const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
+    if (a.CIN == CK && CK <= 32 && CM <= 32 && use_ring_kernels()) {
+#define MMK_RING_CASE(K, M) if (CK == K && CM == M) return launch_conv_ring_epi<K, M>(a, st)
+        MMK_RING_CASE(8, 16); MMK_RING_CASE(8, 32); MMK_RING_CASE(16, 16); MMK_RING_CASE(16, 32);
+        MMK_RING_CASE(32, 16); MMK_RING_CASE(32, 32);
+#undef MMK_RING_CASE
+    }
 #define MMK_CONV_CASE(K, M) if (CK == K && CM == M) return launch_conv<K, M>(a, st)
     MMK_CONV_CASE(8, 16); MMK_CONV_CASE(8, 32); MMK_CONV_CASE(8, 64);
     MMK_CONV_CASE(16, 16); MMK_CONV_CASE(16, 32); MMK_CONV_CASE(16, 64);
