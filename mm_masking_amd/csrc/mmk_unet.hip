@@ -121,11 +121,32 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x)
     return x;
 }
 
-// keep-mask scale of inverted dropout for element index e (0 or 1/(1-p))
-__device__ __forceinline__ float dropout_scale(unsigned seed, unsigned e, float p, float inv_keep)
+// Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index
+// e4 (a multiple of 4): one full avalanche hash per group of 4 + one cheap re-mix, 16 random bits
+// per element compared against thr = round(p * 65536).  (32-bit integer multiplies are quarter
+// rate on the VALU; a hash per element costs more than the convolution of an 8-channel layer.)
+struct DropoutParams {
+    unsigned thr;      // drop when the 16-bit draw is below thr
+    float inv_keep;    // 1 / (1 - thr / 65536): exactly unbiased for the quantised probability
+};
+
+__host__ __device__ inline DropoutParams dropout_params(float p)
 {
-    const unsigned h = hash_u32(e * 0x9E3779B9U + seed);
-    return ((float)(h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+    DropoutParams d;
+    d.thr = (unsigned)(p * 65536.0f + 0.5f);
+    d.inv_keep = d.thr ? 65536.0f / (float)(65536u - d.thr) : 1.0f;
+    return d;
+}
+
+__device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const DropoutParams &d, float (&sc)[4])
+{
+    const unsigned h1 = hash_u32(e4 * 0x9E3779B9U + seed);
+    unsigned h2 = h1 ^ 0x85ebca6bU;
+    h2 ^= h2 >> 16; h2 *= 0x7feb352dU; h2 ^= h2 >> 15;
+    sc[0] = ((h1 & 0xffffu) >= d.thr) ? d.inv_keep : 0.f;
+    sc[1] = ((h1 >> 16) >= d.thr) ? d.inv_keep : 0.f;
+    sc[2] = ((h2 & 0xffffu) >= d.thr) ? d.inv_keep : 0.f;
+    sc[3] = ((h2 >> 16) >= d.thr) ? d.inv_keep : 0.f;
 }
 
 // Software-pipelined, persistent convolution: a block walks the stages (tile, input-channel
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const DropoutParams dp = dropout_params(a.drop_p);
     int chunk = 0;
     load_in(tile, 0);
     load_w(0);
@@ -277,9 +298,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
                                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
+                                float sc[4];
+                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    v[r] *= dropout_scale(a.seed, (unsigned)(p * a.COUT + c0 + r), a.drop_p, inv_keep);
+                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
                             }
                             bf16 *dst = o_y + p * o_C + cl;
                             if (o_src) {
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
 #pragma unroll
     for (int i = 0; i < MT * NT; ++i) reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull;
 
-    const float inv_keep = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const DropoutParams dp = dropout_params(a.drop_p);
     // per-lane output channel bookkeeping (does not depend on the tile)
     float bs[MT][4];
 #pragma unroll

@@ -75,6 +75,13 @@ def wgrad_unpack(dWt, accumulate_into=None):
     return out
 
 
+def dropout_scale(p):
+    """1/keep as the kernels apply it: the drop probability is quantised to 16 bits
+    (csrc/mmk_unet.hip: dropout_params), and the scale is the exact inverse of that keep rate."""
+    thr = int(float(p) * 65536.0 + 0.5)
+    return 65536.0 / (65536 - thr) if thr else 1.0
+
+
 # ----------------------------------------------------------------------------- small wrappers
 def _sp(dev):
     return _lib.stream_ptr(dev)
@@ -210,7 +217,7 @@ class _UNet(torch.autograd.Function):
         ctx.saved_dec = dsaved
         ctx.P = P
         ctx.mask = mask
-        ctx.scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        ctx.scale = dropout_scale(p_drop)
         ctx.n_params = len(params)
         return mask
 

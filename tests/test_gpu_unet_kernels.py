@@ -236,7 +236,7 @@ def _unet_on_hip_activations(model, x, fwd, drop=0.0):
     """fp32 PyTorch autograd graph of the network whose every stored tensor is pinned to the
     value the HIP forward produced: all discrete decisions (ReLU masks, pool arg-max) coincide,
     so parameter gradients must agree up to bf16 rounding of the gradient tensors."""
-    sd = 1.0 / (1.0 - drop)       # inverted-dropout scale of the second conv of every block
+    sd = uh.dropout_scale(drop)   # inverted-dropout scale of the second conv of every block
 
     def conv(t, m, mine, scale=1.0):
         return _forced(F.conv2d(t, m.weight.to(torch.bfloat16).float(), m.bias, padding=1), mine, True, scale)
