@@ -34,8 +34,19 @@ constexpr int CONV_THREADS = 256;
 // pixels for the 16-byte fragment reads (a 128-byte pitch is an 8-way conflict).
 __host__ __device__ constexpr int lds_pitch(int c) { return c >= 16 ? c + 8 : c; }
 __host__ __device__ constexpr int ksteps(int ck) { return ck >= 32 ? 9 * (ck / 32) : (ck == 16 ? 5 : 3); }
+// weight-gradient kernel: input-channel chunk / output-channel group of one block
 __host__ __device__ constexpr int cin_chunk(int cin) { return cin >= 64 ? 64 : cin; }
 __host__ __device__ constexpr int cout_group(int cout) { return cout >= 64 ? 64 : (cout <= 16 ? 16 : cout); }
+// forward / data-gradient kernels: input channels are consumed in chunks of conv_ck, one block
+// produces conv_cm output channels.  Layers with >= 64 channels on either side (and 32 -> >= 64)
+// run on conv3x3_deep_kernel (8 waves, up to 128 output channels per block).
+__host__ __device__ constexpr int conv_ck(int cin) { return cin >= 32 ? 32 : cin; }
+__host__ __device__ constexpr bool conv_is_deep(int cin, int cout) { return cin >= 64 || (cin == 32 && cout >= 64); }
+__host__ __device__ constexpr int conv_cm(int cin, int cout)
+{
+    if (conv_is_deep(cin, cout)) return cout >= 128 ? 128 : (cout <= 16 ? 16 : cout);
+    return cout >= 64 ? 64 : (cout <= 16 ? 16 : cout);
+}
 
 // (tap, channel offset inside the chunk) of the 8 consecutive k values lane `l` holds in k-step `s`.
 template <int CK>
@@ -64,7 +75,7 @@ __global__ void pack_conv_weights_kernel(const float *__restrict__ W, int COUT, 
     if (e >= total) return;
     const int co_n = transposed ? CIN : COUT;   // channels produced by the packed operator
     const int ci_n = transposed ? COUT : CIN;   // channels consumed
-    const int CK = cin_chunk(ci_n), CM = cout_group(co_n);
+    const int CK = conv_ck(ci_n), CM = conv_cm(ci_n, co_n);
     const int NS = ksteps(CK), MT = CM / 16;
     const int nchunk = ci_n / CK;
     int r = e;
@@ -549,6 +560,244 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
     return epi ? launch_conv_ring<CK, CM, RD, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Layers with >= 64 channels: 8 waves per block (two per SIMD, so one wave's LDS traffic and
+// epilogue overlap the other's MFMAs), input channels in chunks of 32 (one k-step per tap),
+// up to 128 output channels per block, and a tile of TH rows x NT*16 pixels whose width is
+// picked per layer (NT = 3 for 40-pixel rows, 5 for 80 / 160) so that no MFMA column is wasted
+// on padding.  Wave (wm, wn) owns output channels [wm*MT*16, +MT*16) of tile row wn.
+constexpr int DEEP_THREADS = 512;
+
+template <int BM, int NT>
+struct DeepCfg {
+    static constexpr int WM = BM >= 128 ? 2 : 1;          // waves along the output channels
+    static constexpr int WN = 8 / WM;                     // waves along the tile rows
+    static constexpr int MT = BM / 16 / WM;               // 16-channel tiles per wave
+    static constexpr int MTB = BM / 16;                   // ... per block
+    static constexpr int TH = WN, TWD = NT * 16;
+    static constexpr int HT = TH + 2, WT = TWD + 2;
+    static constexpr int CK = 32, PK = 40, NS = 9, GPP = 4;
+    static constexpr int NIN = HT * WT * GPP;
+    static constexpr int NW = NS * MTB * 64;
+    static constexpr int RIN = (NIN + DEEP_THREADS - 1) / DEEP_THREADS;
+    static constexpr int RW = (NW + DEEP_THREADS - 1) / DEEP_THREADS;
+    static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16);
+};
+
+template <int BM, int NT>
+__global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
+{
+    using C = DeepCfg<BM, NT>;
+    constexpr int MT = C::MT, MTB = C::MTB, PK = C::PK, WT = C::WT, HT = C::HT, GPP = C::GPP;
+    constexpr int NIN = C::NIN, NW = C::NW, RIN = C::RIN, RW = C::RW, NS = C::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *in_tile = reinterpret_cast<bf16 *>(smem);
+    bf16 *w_lds = in_tile + HT * WT * PK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / C::WN, wn = wv % C::WN;
+    const int tiles_x = (a.W + C::TWD - 1) / C::TWD, tiles_y = (a.H + C::TH - 1) / C::TH;
+    const int tpi = tiles_x * tiles_y;
+    const int group = blockIdx.y;
+    const int nchunk = a.CIN / 32;
+
+    const int xcd = blockIdx.x & 7, nb = gridDim.x >> 3;
+    const int t_begin = xcd * tiles_per_xcd;
+    const int t_end = (t_begin + tiles_per_xcd < total_tiles) ? t_begin + tiles_per_xcd : total_tiles;
+    int tile = t_begin + (blockIdx.x >> 3);
+    if (tile >= t_end) return;
+
+    u32x4 rin[RIN], rw[RW];
+    int g_dy[RIN], g_dx[RIN], g_c[RIN];
+#pragma unroll
+    for (int i = 0; i < RIN; ++i) {
+        int g = tid + i * DEEP_THREADS;
+        g = g < NIN ? g : NIN - 1;
+        const int pix = g / GPP;
+        g_dy[i] = pix / WT - 1;
+        g_dx[i] = pix % WT - 1;
+        g_c[i] = (g % GPP) * 8;
+    }
+    auto load_in = [&](int t, int chunk) {
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * C::TWD, ty0 = tyi * C::TH;
+        const int c0 = chunk * 32;
+        // a 32-channel chunk lies entirely in one of the two concatenated inputs
+        const bool in1 = c0 < a.C1;
+        const bf16 *xb = in1 ? a.x1 : a.x2;
+        const int xc = in1 ? a.C1 : a.C2, cb = in1 ? c0 : c0 - a.C1;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int yy = ty0 + g_dy[i], xx = tx0 + g_dx[i];
+            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(xb + p * xc + cb + g_c[i]) : &g_zero16;
+            rin[i] = *sp;
+        }
+    };
+    auto load_w = [&](int chunk) {
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NW * 8);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * DEEP_THREADS;
+            rw[i] = wsrc[g < NW ? g : NW - 1];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const DropoutParams dp = dropout_params(a.drop_p);
+    // fragment addresses that do not depend on the stage
+    const bf16 *b_base = in_tile + ((size_t)(wn * WT + (lane & 15))) * PK + 8 * (lane >> 4);
+    const bf16 *a_base = w_lds + ((size_t)(wm * MT) * 64 + lane) * 8;
+
+    int chunk = 0;
+    load_in(tile, 0);
+    load_w(0);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int g = tid + i * DEEP_THREADS;
+            if (g < NIN) *reinterpret_cast<u32x4 *>(in_tile + (size_t)(g / GPP) * PK + (g % GPP) * 8) = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * DEEP_THREADS;
+            if (g < NW) reinterpret_cast<u32x4 *>(w_lds)[g] = rw[i];
+        }
+        __syncthreads();
+        int ntile = tile, nck = chunk + 1;
+        if (nck == nchunk) {
+            nck = 0;
+            ntile = tile + nb;
+        }
+        const bool has_next = ntile < t_end;
+        {
+            const int lt = has_next ? ntile : tile;     // (clamped: the loads stay unconditional)
+            load_in(lt, nck);
+            load_w(nck);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ty = s / 3, tx = s % 3;
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                bf[n] = *reinterpret_cast<const bf16x8 *>(b_base + ((size_t)(ty * WT + n * 16 + tx)) * PK);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(a_base + ((size_t)(s * MTB + m) * 64) * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (chunk == nchunk - 1) {
+            const int b = tile / tpi, tr = tile - b * tpi;
+            const int tyi = tr / tiles_x;
+            const int tx0 = (tr - tyi * tiles_x) * C::TWD, yy = tyi * C::TH + wn;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int c0 = group * BM + (wm * MT + m) * 16 + (lane >> 4) * 4;
+                if (c0 < a.COUT) {
+                    const bool firstp = c0 < a.o1.C;
+                    bf16 *o_y = firstp ? a.o1.y : a.o2.y;
+                    const bf16 *o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
+                    const int o_C = firstp ? a.o1.C : a.o2.C;
+                    const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
+                    const float o_scale = firstp ? a.o1.scale : a.o2.scale;
+                    const int cl = firstp ? c0 : c0 - a.o1.C;
+                    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bs[r] = a.bias[c0 + r];
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int xx = tx0 + n * 16 + (lane & 15);
+                        if (yy < a.H && xx < a.W) {
+                            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = acc[m][n][r] + bs[r];
+                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            if (a.drop_p > 0.f) {
+                                float sc[4];
+                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                            }
+                            bf16 *dst = o_y + p * o_C + cl;
+                            if (o_src) {
+                                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o_src + p * o_C + cl);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f;
+                            }
+                            if (o_acc) {
+                                const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+                            }
+                            bf16x4 outv;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
+                            *reinterpret_cast<bf16x4 *>(dst) = outv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        tile = ntile;
+        chunk = nck;
+    }
+}
+
+template <int BM, int NT>
+int launch_conv_deep(const ConvArgs &a, hipStream_t st)
+{
+    using C = DeepCfg<BM, NT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    MMK_CHECK_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        if (C::SMEM > 64 * 1024)
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)C::SMEM));
+        attr_set[dev & 63] = true;
+    }
+    const int tiles = ((a.W + C::TWD - 1) / C::TWD) * ((a.H + C::TH - 1) / C::TH);
+    const int groups = (a.COUT + BM - 1) / BM;
+    const int total = tiles * a.B;
+    const int per_xcd = (total + 7) / 8;
+    int nb = 32 / groups;                                    // one 8-wave block per CU, 32 CUs per XCD
+    nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
+    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
+{
+    const int BM = conv_cm(a.CIN, a.COUT);
+    const bool narrow = a.W <= 48;          // NT = 3 (48-pixel tile rows) wastes less than NT = 5 there
+#define MMK_DEEP_CASE(M) if (BM == M) return narrow ? launch_conv_deep<M, 3>(a, st) : launch_conv_deep<M, 5>(a, st)
+    MMK_DEEP_CASE(16); MMK_DEEP_CASE(32); MMK_DEEP_CASE(64); MMK_DEEP_CASE(128);
+#undef MMK_DEEP_CASE
+    mmk::set_error("mmk_conv3x3: unsupported channel counts CIN=%d COUT=%d", a.CIN, a.COUT);
+    return MMK_ERR_ARG;
+}
+
 bool use_ring_kernels()
 {
     static int v = -1;
@@ -561,8 +810,9 @@ bool use_ring_kernels()
 
 int dispatch_conv(const ConvArgs &a, hipStream_t st)
 {
-    const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
-    if (a.CIN == CK && CK <= 32 && CM <= 32 && use_ring_kernels()) {
+    if (conv_is_deep(a.CIN, a.COUT)) return dispatch_conv_deep(a, st);
+    const int CK = conv_ck(a.CIN), CM = conv_cm(a.CIN, a.COUT);
+    if (a.CIN == CK && CM <= 32 && use_ring_kernels()) {
 #define MMK_RING_CASE(K, M) if (CK == K && CM == M) return launch_conv_ring_epi<K, M>(a, st)
         MMK_RING_CASE(8, 16); MMK_RING_CASE(8, 32); MMK_RING_CASE(16, 16); MMK_RING_CASE(16, 32);
         MMK_RING_CASE(32, 16); MMK_RING_CASE(32, 32);
@@ -571,8 +821,7 @@ int dispatch_conv(const ConvArgs &a, hipStream_t st)
 #define MMK_CONV_CASE(K, M) if (CK == K && CM == M) return launch_conv<K, M>(a, st)
     MMK_CONV_CASE(8, 16); MMK_CONV_CASE(8, 32); MMK_CONV_CASE(8, 64);
     MMK_CONV_CASE(16, 16); MMK_CONV_CASE(16, 32); MMK_CONV_CASE(16, 64);
-    MMK_CONV_CASE(32, 16); MMK_CONV_CASE(32, 32); MMK_CONV_CASE(32, 64);
-    MMK_CONV_CASE(64, 16); MMK_CONV_CASE(64, 32); MMK_CONV_CASE(64, 64);
+    MMK_CONV_CASE(32, 16); MMK_CONV_CASE(32, 32);
 #undef MMK_CONV_CASE
     mmk::set_error("mmk_conv3x3: unsupported channel counts CIN=%d COUT=%d", a.CIN, a.COUT);
     return MMK_ERR_ARG;
@@ -1144,7 +1393,7 @@ extern "C" size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t tr
 {
     const int co_n = transposed ? cin : cout, ci_n = transposed ? cout : cin;
     if (!chan_ok(co_n) || !chan_ok(ci_n)) return 0;
-    const int CK = cin_chunk(ci_n), CM = cout_group(co_n);
+    const int CK = conv_ck(ci_n), CM = conv_cm(ci_n, co_n);
     const int groups = (co_n + CM - 1) / CM, chunks = ci_n / CK;
     return (size_t)groups * chunks * ksteps(CK) * (CM / 16) * 512;
 }

@@ -1,4 +1,4 @@
-"""Run the full-res conv probes against an experimental build (development tool):
+"""Run deep-layer conv probes against an experimental build (development tool):
    python tools/exp_variants.py build_exp/lib_X.so"""
 import sys
 sys.path.insert(0, ".")
@@ -8,15 +8,12 @@ import torch
 from mm_masking_amd import unet_hip as uh
 from tools.bench_layers import rnd, timeit, DEV
 
-B, H = 32, 640
+B = 32
 out = []
-for cin, co in [(8, 8), (16, 16), (16, 8)]:
+for cin, co, H in [(64, 64, 160), (128, 128, 80), (256, 256, 40), (256, 128, 40)]:
     x = rnd(B, H, H, cin)
     w = torch.randn(co, cin, 3, 3, device=DEV) / (3 * cin ** 0.5)
     wp = uh.pack_weights(w)
     y = torch.empty(B, H, H, co, dtype=torch.bfloat16, device=DEV)
-    out.append("%d>%d %.0f" % (cin, co, timeit(lambda: uh.conv3x3(x, wp, co, out=y))))
-x = rnd(B, 80, 80, 128); w = torch.randn(128, 128, 3, 3, device=DEV) / 30; wp = uh.pack_weights(w)
-y = torch.empty(B, 80, 80, 128, dtype=torch.bfloat16, device=DEV)
-out.append("128>128@80 %.0f" % timeit(lambda: uh.conv3x3(x, wp, 128, out=y)))
+    out.append("%d>%d@%d %.0f" % (cin, co, H, timeit(lambda: uh.conv3x3(x, wp, co, out=y))))
 print(sys.argv[1], " | ".join(out))
