@@ -851,6 +851,16 @@ __device__ __forceinline__ i32x2 tr_read(unsigned addr)
     return v;
 }
 
+// same with the offset in the instruction's 16-bit immediate field (no address register per read)
+template <int OFF>
+__device__ __forceinline__ i32x2 tr_read_o(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    i32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ bf16x8 frag_from(i32x2 lo, i32x2 hi)
 {
     i32x4 t = {lo.x, lo.y, hi.x, hi.y};
@@ -1073,8 +1083,210 @@ int launch_wgrad(const WgradArgs &a, hipStream_t st)
     return MMK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the layers with >= 64 channels on both sides: 8 waves per block (two per
+// SIMD) on a 64 (co) x 64 (ci) x 9 (taps) slice.  Wave (wm, wc) owns 2 co-tiles x 1 ci-tile
+// x 9 taps.  The contraction walks the halo rows rho of a tile: the three x fragments of row
+// rho (tx = 0..2) meet the g fragments of the tile rows rho, rho-1, rho-2 (ty = 0, 1, 2), so
+// every x fragment is read from LDS once instead of three times (10 transposing reads per 18
+// MFMAs).  Fragment reads of row rho+1 are in flight while row rho is on the matrix cores.
+constexpr int WGD_THREADS = 512;
+
+__global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const WgradArgs a)
+{
+    constexpr int CK = 64, CM = 64, PK = 72, PG = 72;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // (HT*WT + 8) * PK
+    bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // (TH*TW + 8) * PG
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 2, wc = wv & 3;
+    const int chunk = blockIdx.y, group = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    f32x4 acc[3][3][2];
+    f32x4 accb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) acc[ty][tx][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+    const unsigned xb0 = lds_addr(x_tile) + (unsigned)(((8 * g4 + q) * PK + wc * 16 + 4 * pp) * 2);
+    const unsigned gb0 = lds_addr(g_tile) + (unsigned)(((8 * g4 + q) * PG + wm * 32 + 4 * pp) * 2);
+
+    // register staging of the next tile (same scheme as conv3x3_wgrad_kernel)
+    constexpr int GPP = CK / 8;
+    constexpr int NIN = HT * WT * GPP;
+    constexpr int RIN = (NIN + WGD_THREADS - 1) / WGD_THREADS;
+    constexpr int GPG = CM / 8;
+    constexpr int NG = TH * TW * GPG;
+    constexpr int RG = (NG + WGD_THREADS - 1) / WGD_THREADS;
+    u32x4 rin[RIN], rg[RG];
+    // `tv` is the thread index behind an opaque asm: everything derived from it is recomputed per tile
+    // (a few VALU instructions) instead of being hoisted out of the tile loop into ~50 live registers
+    auto load_tile = [&](int t) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int c0 = chunk * CK;
+        const bool in1 = c0 < a.C1;                     // a 64-channel chunk lies in one of the two inputs
+        const bf16 *xb = in1 ? a.x1 : a.x2;
+        const int xc = in1 ? a.C1 : a.C2, cb = in1 ? c0 : c0 - a.C1;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            int gi = tv + i * WGD_THREADS;
+            gi = gi < NIN ? gi : NIN - 1;
+            const int pix = gi / GPP, gc = gi % GPP;
+            const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
+            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(xb + p * xc + cb + gc * 8) : &g_zero16;
+            rin[i] = *sp;
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int gi = tv + i * WGD_THREADS;
+            gi = gi < NG ? gi : NG - 1;
+            const int pix = gi / GPG, gc = gi % GPG;
+            const int yy = ty0 + pix / TW, xx = tx0 + pix % TW;
+            const bool ok = yy < a.H && xx < a.W;
+            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(a.g + p * a.COUT + group * CM + gc * 8) : &g_zero16;
+            rg[i] = *sp;
+        }
+    };
+    auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int gi = tv + i * WGD_THREADS;
+            if (gi < NIN) *reinterpret_cast<u32x4 *>(x_tile + (size_t)(gi / GPP) * PK + (gi % GPP) * 8) = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gi = tv + i * WGD_THREADS;
+            if (gi < NG) *reinterpret_cast<u32x4 *>(g_tile + (size_t)(gi / GPG) * PG + (gi % GPG) * 8) = rg[i];
+        }
+    };
+
+    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        {
+            const int nt = t + (int)gridDim.x;
+            load_tile(nt < total_tiles ? nt : t);       // (clamped: the loads stay unconditional)
+        }
+        // fragment registers: x row rho in fb, g rows rho-2 .. rho in a ring of 3.  The reads of row
+        // rho+1 are issued right behind row rho's MFMAs (which have read their operands by then) and
+        // land while the matrix pipe works through them / the SIMD's other wave runs.  Every read
+        // carries its offset as an immediate: ~100 distinct addresses would otherwise be hoisted
+        // into registers and spilled.
+        i32x2 fb[3][2], fa[3][2][2];
+#define WGD_ISSUE(RHO)                                                                                   \
+    {                                                                                                    \
+        fb[0][0] = tr_read_o<(((RHO) * WT + 0) * PK) * 2>(xb0);                                          \
+        fb[0][1] = tr_read_o<(((RHO) * WT + 0) * PK + 4 * PK) * 2>(xb0);                                 \
+        fb[1][0] = tr_read_o<(((RHO) * WT + 1) * PK) * 2>(xb0);                                          \
+        fb[1][1] = tr_read_o<(((RHO) * WT + 1) * PK + 4 * PK) * 2>(xb0);                                 \
+        fb[2][0] = tr_read_o<(((RHO) * WT + 2) * PK) * 2>(xb0);                                          \
+        fb[2][1] = tr_read_o<(((RHO) * WT + 2) * PK + 4 * PK) * 2>(xb0);                                 \
+        if ((RHO) < TH) {                                                                                \
+            constexpr int R_ = (RHO) < TH ? (RHO) : 0;                                                   \
+            fa[R_ % 3][0][0] = tr_read_o<((R_ * TW) * PG) * 2>(gb0);                                     \
+            fa[R_ % 3][0][1] = tr_read_o<((R_ * TW) * PG + 4 * PG) * 2>(gb0);                            \
+            fa[R_ % 3][1][0] = tr_read_o<((R_ * TW) * PG + 16) * 2>(gb0);                                \
+            fa[R_ % 3][1][1] = tr_read_o<((R_ * TW) * PG + 16 + 4 * PG) * 2>(gb0);                       \
+        }                                                                                                \
+    }
+#define WGD_STEP(RHO)                                                                                    \
+    {                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        bf16x8 bfr[3];                                                                                   \
+        _Pragma("unroll") for (int tx = 0; tx < 3; ++tx) bfr[tx] = frag_from(fb[tx][0], fb[tx][1]);      \
+        _Pragma("unroll") for (int ty = 0; ty < 3; ++ty) {                                               \
+            const int r = (RHO) - ty; /* tile row whose g meets x row rho at tap row ty */               \
+            if (r >= 0 && r < TH) {                                                                      \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                          \
+                    const bf16x8 af = frag_from(fa[r % 3][m][0], fa[r % 3][m][1]);                       \
+                    _Pragma("unroll") for (int tx = 0; tx < 3; ++tx)                                     \
+                        acc[ty][tx][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[tx], acc[ty][tx][m], 0, 0, 0); \
+                    if (ty == 0 && wc == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0); \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((RHO) + 1 < HT) WGD_ISSUE(((RHO) + 1 < HT ? (RHO) + 1 : 0));                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    }
+        WGD_ISSUE(0);
+        WGD_STEP(0) WGD_STEP(1) WGD_STEP(2) WGD_STEP(3) WGD_STEP(4)
+        WGD_STEP(5) WGD_STEP(6) WGD_STEP(7) WGD_STEP(8) WGD_STEP(9)
+        static_assert(HT == 10, "WGD_STEP expansion above covers 10 halo rows");
+#undef WGD_STEP
+#undef WGD_ISSUE
+    }
+
+    // ---- one atomic pass per block
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = group * CM + (wm * 2 + m) * 16 + g4 * 4 + rr;
+            const int ci = chunk * CK + wc * 16 + i16;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx)
+                    atomicAdd(&a.dWt[((size_t)(ty * 3 + tx) * a.COUT + co) * a.CIN + ci], acc[ty][tx][m][rr]);
+            if (a.db && wc == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
+        }
+    }
+}
+
+int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
+{
+    const size_t smem = ((size_t)(HT * WT + 8) * 72 + (size_t)(TH * TW + 8) * 72) * sizeof(bf16);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    MMK_CHECK_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set[dev & 63] = true;
+    }
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+    const int chunks = a.CIN / 64, groups = a.COUT / 64;
+    int spatial = 256 / (chunks * groups);            // one 8-wave block per CU
+    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    hipLaunchKernelGGL(conv3x3_wgrad_deep_kernel, dim3(spatial, chunks, groups), dim3(WGD_THREADS), smem, st, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
 int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
 {
+    static int deep = -1;
+    if (deep < 0) {
+        const char *e = getenv("MMK_WGRAD_DEEP");
+        deep = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (deep && a.CIN % 64 == 0 && a.COUT % 64 == 0 && a.C1 % 64 == 0) return launch_wgrad_deep(a, st);
     const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
 #define MMK_WG_CASE(K, M) if (CK == K && CM == M) return launch_wgrad<K, M>(a, st)
     MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);

@@ -125,6 +125,19 @@ def test_conv3x3_wgrad_concat():
     assert (dW - w.grad).abs().max().item() < 2e-3 * w.grad.abs().max().item() + 1e-3
 
 
+def test_conv3x3_wgrad_concat_deep():
+    """Concatenated input of the decoder's second application at 64 / 128 channels (8-wave kernel)."""
+    B, H, W = 2, 20, 40
+    for cs in (64, 128):
+        xa, xb = _rand_nhwc(B, H, W, cs, 11), _rand_nhwc(B, H, W, cs, 12)
+        gy = _rand_nhwc(B, H, W, cs, 13)
+        w = torch.zeros(cs, 2 * cs, 3, 3, device=DEV, requires_grad=True)
+        y = F.conv2d(torch.cat([xa, xb], 3).float().permute(0, 3, 1, 2), w, padding=1)
+        y.backward(gy.float().permute(0, 3, 1, 2))
+        dW = uh.wgrad_unpack(uh.conv3x3_wgrad(xa, gy, cs, x2=xb))
+        assert (dW - w.grad).abs().max().item() < 2e-3 * w.grad.abs().max().item() + 1e-3
+
+
 def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
