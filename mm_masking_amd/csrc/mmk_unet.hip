@@ -1396,6 +1396,130 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
     }
 }
 
+
+// Fast paths for W % 4 == 0: one thread per 4 horizontally adjacent pixels.  The three input rows
+// are fetched as one 16-byte load + two edge scalars each (9 loads per 4 pixels instead of 36) and
+// the index arithmetic is paid once per quad.
+__device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, int x0, int H, int W, float (&v)[6])
+{
+    if (y2 < 0 || y2 >= H) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = 0.f;
+        return;
+    }
+    const float *row = xc + (size_t)y2 * W;
+    const float4 m = *reinterpret_cast<const float4 *>(row + x0);
+    v[0] = (x0 > 0) ? row[x0 - 1] : 0.f;
+    v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
+    v[5] = (x0 + 4 < W) ? row[x0 + 4] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = (float)(bf16)v[i];       // bf16 operands as on the MFMA path
+}
+
+__global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
+                                                            const float *__restrict__ bias, int B, int H, int W,
+                                                            bf16 *__restrict__ y)
+{
+    __shared__ float ws[8 * 4 * 9 + 8];
+    for (int i = threadIdx.x; i < 8 * CIN * 9; i += blockDim.x) ws[i] = Wt[i];
+    if (threadIdx.x < 8) ws[8 * 4 * 9 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int Wq = W >> 2;
+    const int nq = B * H * Wq;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += gridDim.x * blockDim.x) {
+        const int q = e % Wq, by = e / Wq;
+        const int yy = by % H, b = by / H;
+        const int x0 = q * 4;
+        float acc[4][8];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[px][co] = ws[8 * 4 * 9 + co];
+        for (int c = 0; c < CIN; ++c) {
+            const float *xc = x + ((size_t)b * CIN + c) * H * W;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[6];
+                load_row6(xc, yy + dy - 1, x0, H, W, v);
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        const float w = ws[(co * CIN + c) * 9 + dy * 3 + tx];
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[px][co] += v[px + tx] * w;
+                    }
+                }
+            }
+        }
+        bf16 *dst = y + ((size_t)by * W + x0) * 8;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            bf16x8 o;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) o[co] = (bf16)fmaxf(acc[px][co], 0.f);
+            *reinterpret_cast<bf16x8 *>(dst + px * 8) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
+                                                                  int B, int H, int W, float *__restrict__ dW,
+                                                                  float *__restrict__ db)
+{
+    __shared__ float red[4][80];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Wq = W >> 2;
+    const int nq = B * H * Wq;
+    for (int c = 0; c < CIN; ++c) {
+        float acc[80];
+#pragma unroll
+        for (int i = 0; i < 80; ++i) acc[i] = 0.f;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += gridDim.x * blockDim.x) {
+            const int q = e % Wq, by = e / Wq;
+            const int yy = by % H, b = by / H;
+            const int x0 = q * 4;
+            const float *xc = x + ((size_t)b * CIN + c) * H * W;
+            float gf[4][8];
+            const bf16 *gp = g + ((size_t)by * W + x0) * 8;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(gp + px * 8);
+#pragma unroll
+                for (int co = 0; co < 8; ++co) gf[px][co] = (float)gv[co];
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[6];
+                load_row6(xc, yy + dy - 1, x0, H, W, v);
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[co * 9 + dy * 3 + tx] += gf[px][co] * v[px + tx];
+            }
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[72 + co] += (gf[0][co] + gf[1][co]) + (gf[2][co] + gf[3][co]);
+        }
+#pragma unroll
+        for (int i = 0; i < 80; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wv][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 80) {
+            const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            const int i = threadIdx.x;
+            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], v);
+            else if (c == 0 && db) atomicAdd(&db[i - 72], v);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // 2x2 / stride 2 max pooling (nn.MaxPool2d(2,2), icp_weight_policy.py:122-123), NHWC bf16,
 // one thread per (output pixel, 8-channel granule).
@@ -1468,13 +1592,12 @@ __device__ __forceinline__ void up_coord(int o, float r, int n_src, int &i0, int
 __global__ void upsample_fwd_kernel(const bf16 *__restrict__ x, int B, int Hs, int Ws, int C, int Ho, int Wo,
                                     bf16 *__restrict__ y)
 {
+    // grid: x = (output pixel, granule) of one output row, y = output row, z = image
     const int G = C / 8;
-    const size_t n = (size_t)B * Ho * Wo * G;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int gc = (int)(e % G);
-    const size_t po = e / G;
-    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), b = (int)(po / ((size_t)Wo * Ho));
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Wo * G) return;
+    const int gc = e % G, xo = e / G;
+    const int yo = blockIdx.y, b = blockIdx.z;
     const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
     const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
     int y0, y1, x0, x1;
@@ -1490,21 +1613,22 @@ __global__ void upsample_fwd_kernel(const bf16 *__restrict__ x, int B, int Hs, i
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         o[j] = (bf16)(ly0 * (lx0 * (float)a00[j] + lx1 * (float)a01[j]) + ly1 * (lx0 * (float)a10[j] + lx1 * (float)a11[j]));
-    *reinterpret_cast<bf16x8 *>(y + po * C + gc * 8) = o;
+    *reinterpret_cast<bf16x8 *>(y + (((size_t)b * Ho + yo) * Wo + xo) * C + gc * 8) = o;
 }
 
 // Gather form of the adjoint (deterministic, no atomics): each source pixel sums the output
 // pixels it was interpolated into; optional ReLU/dropout factor of the source activation.
+// The weights along x do not depend on the output row: they are worked out once per thread.
 __global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, int Ws, int C, int Ho, int Wo,
                                     const bf16 *__restrict__ relu_src, float scale, bf16 *__restrict__ gx)
 {
+    // grid: x = (source pixel, granule) of one source row, y = source row, z = image
+    constexpr int MAXW = 8;
     const int G = C / 8;
-    const size_t n = (size_t)B * Hs * Ws * G;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int gc = (int)(e % G);
-    const size_t ps = e / G;
-    const int xs = (int)(ps % Ws), ys = (int)((ps / Ws) % Hs), b = (int)(ps / ((size_t)Ws * Hs));
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Ws * G) return;
+    const int gc = e % G, xs = e / G;
+    const int ys = blockIdx.y, b = blockIdx.z;
     const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
     const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
     const int ylo = (rh > 0.f) ? max(0, (int)floorf((float)(ys - 1) / rh) - 1) : 0;
@@ -1512,24 +1636,49 @@ __global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, 
     const int xlo = (rw > 0.f) ? max(0, (int)floorf((float)(xs - 1) / rw) - 1) : 0;
     const int xhi = (rw > 0.f) ? min(Wo - 1, (int)ceilf((float)(xs + 1) / rw) + 1) : Wo - 1;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool small = (xhi - xlo + 1) <= MAXW;          // always true for up-sampling factors >= ~1.5
+    float wxs[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        const int xo = xlo + k;
+        int x0, x1;
+        float m0, m1;
+        up_coord(xo, rw, Ws, x0, x1, m0, m1);
+        const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
+        wxs[k] = (xo <= xhi) ? wx : 0.f;
+    }
     for (int yo = ylo; yo <= yhi; ++yo) {
         int y0, y1;
         float l0, l1;
         up_coord(yo, rh, Hs, y0, y1, l0, l1);
         const float wy = ((y0 == ys) ? l0 : 0.f) + ((y1 == ys) ? l1 : 0.f);
         if (wy == 0.f) continue;
-        for (int xo = xlo; xo <= xhi; ++xo) {
-            int x0, x1;
-            float m0, m1;
-            up_coord(xo, rw, Ws, x0, x1, m0, m1);
-            const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
-            if (wx == 0.f) continue;
-            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gy + (((size_t)b * Ho + yo) * Wo + xo) * C + gc * 8);
-            const float w = wy * wx;
+        const bf16 *grow = gy + (((size_t)b * Ho + yo) * Wo) * C + gc * 8;
+        if (small) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
+            for (int k = 0; k < MAXW; ++k) {
+                if (wxs[k] != 0.f) {
+                    const bf16x8 g = *reinterpret_cast<const bf16x8 *>(grow + (size_t)(xlo + k) * C);
+                    const float w = wy * wxs[k];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
+                }
+            }
+        } else {
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int x0, x1;
+                float m0, m1;
+                up_coord(xo, rw, Ws, x0, x1, m0, m1);
+                const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
+                if (wx == 0.f) continue;
+                const bf16x8 g = *reinterpret_cast<const bf16x8 *>(grow + (size_t)xo * C);
+                const float w = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
+            }
         }
     }
+    const size_t ps = ((size_t)b * Hs + ys) * Ws + xs;
     bf16x8 o;
     if (relu_src) {
         const bf16x8 sv = *reinterpret_cast<const bf16x8 *>(relu_src + ps * C + gc * 8);
@@ -1675,6 +1824,12 @@ extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const
     MMK_REQUIRE(x && W && y, "mmk_conv_first: NULL pointer");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first: bad shape (cin must be 1..4)");
     const size_t npix = (size_t)B * H * Wd;
+    if (Wd % 4 == 0 && npix < (1u << 31)) {
+        const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_first_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, B, H, Wd, (bf16 *)y);
+        MMK_LAUNCH_CHECK();
+        return MMK_OK;
+    }
     const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 8192);
     hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, B, H, Wd, (bf16 *)y);
     MMK_LAUNCH_CHECK();
@@ -1687,6 +1842,13 @@ extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, 
     MMK_REQUIRE(x && g && dW, "mmk_conv_first_wgrad: NULL pointer");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first_wgrad: bad shape");
     const size_t npix = (size_t)B * H * Wd;
+    if (Wd % 4 == 0 && npix < (1u << 31)) {
+        const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(conv_first_wgrad_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B,
+                           H, Wd, dW, db);
+        MMK_LAUNCH_CHECK();
+        return MMK_OK;
+    }
     const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 1024);
     hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B, H,
                        Wd, dW, db);
@@ -1719,9 +1881,9 @@ extern "C" int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws
                                 void *stream)
 {
     MMK_REQUIRE(x && y && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_fwd: bad argument");
-    const size_t n = (size_t)B * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, Hs, Ws, C,
-                       Ho, Wo, (bf16 *)y);
+    MMK_REQUIRE(Ho <= 65535 && B <= 65535, "mmk_upsample_fwd: shape exceeds the launch grid");
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(nblk((size_t)Wo * (C / 8), 256), Ho, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16 *)x, B, Hs, Ws, C, Ho, Wo, (bf16 *)y);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -1730,9 +1892,9 @@ extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t W
                                 const void *relu_src, float scale, void *gx, void *stream)
 {
     MMK_REQUIRE(gy && gx && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_bwd: bad argument");
-    const size_t n = (size_t)B * Hs * Ws * (C / 8);
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, B, Hs, Ws, C,
-                       Ho, Wo, (const bf16 *)relu_src, scale, (bf16 *)gx);
+    MMK_REQUIRE(Hs <= 65535 && B <= 65535, "mmk_upsample_bwd: shape exceeds the launch grid");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(nblk((size_t)Ws * (C / 8), 256), Hs, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16 *)gy, B, Hs, Ws, C, Ho, Wo, (const bf16 *)relu_src, scale, (bf16 *)gx);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

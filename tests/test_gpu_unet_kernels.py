@@ -145,12 +145,28 @@ def _nhwc(x_nchw):
 def test_aux_kernels_vs_torch():
     g = torch.Generator().manual_seed(0)
     # first layer
-    x = torch.rand(2, 3, 20, 36, generator=g).to(DEV)
-    w = (torch.randn(8, 3, 3, 3, generator=g) / 5).to(DEV)
-    b = torch.randn(8, generator=g).to(DEV)
-    y = uh.conv_first(x, w, b)
-    ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), b, padding=1)).permute(0, 2, 3, 1)
-    assert (y.float() - ref).abs().max().item() < 0.03
+    import ctypes
+    from mm_masking_amd import _lib
+    for wd in (36, 37):           # W % 4 == 0: 4-pixels-per-thread kernels; otherwise the generic ones
+        x = torch.rand(2, 3, 20, wd, generator=g).to(DEV)
+        w = (torch.randn(8, 3, 3, 3, generator=g) / 5).to(DEV)
+        b = torch.randn(8, generator=g).to(DEV)
+        y = uh.conv_first(x, w, b)
+        xq = x.to(torch.bfloat16).float()
+        wq = w.to(torch.bfloat16).float().requires_grad_(True)
+        bq = b.clone().requires_grad_(True)
+        pre = F.conv2d(xq, wq, bq, padding=1)
+        ref = F.relu(pre).permute(0, 2, 3, 1)
+        assert (y.float() - ref).abs().max().item() < 0.03
+        gz = (torch.randn(2, 20, wd, 8, generator=g) / 4).to(DEV).to(torch.bfloat16)
+        pre.backward(gz.float().permute(0, 3, 1, 2))
+        dw = torch.zeros(8, 3, 3, 3, device=DEV)
+        db = torch.zeros(8, device=DEV)
+        _lib.check(_lib.lib().mmk_conv_first_wgrad(ctypes.c_void_p(x.data_ptr()), 3, ctypes.c_void_p(gz.data_ptr()), 2, 20, wd,
+                                                   ctypes.c_void_p(dw.data_ptr()), ctypes.c_void_p(db.data_ptr()),
+                                                   _lib.stream_ptr(DEV)))
+        assert (dw - wq.grad).abs().max().item() < 2e-3 * wq.grad.abs().max().item() + 1e-3
+        assert (db - bq.grad).abs().max().item() < 2e-3 * bq.grad.abs().max().item() + 1e-3
     # max pool fwd / bwd (with the fused relu+dropout factor)
     d = F.relu(torch.randn(2, 16, 12, 20, generator=g)).to(DEV)
     dn = _nhwc(d)
@@ -164,7 +180,7 @@ def test_aux_kernels_vs_torch():
     want = (dref.grad * (dref > 0) * 1.25).permute(0, 2, 3, 1)
     assert (gz.float() - want).abs().max().item() < 0.02
     # bilinear upsample (align_corners) fwd / bwd
-    for (hs, ws, ho, wo) in [(20, 20, 40, 40), (5, 7, 10, 14), (40, 40, 80, 80), (6, 6, 13, 11)]:
+    for (hs, ws, ho, wo) in [(20, 20, 40, 40), (5, 7, 10, 14), (40, 40, 80, 80), (6, 6, 13, 11), (3, 4, 30, 44)]:
         xs = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
         xr = xs.to(torch.bfloat16).float().requires_grad_(True)
         ur = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=True)
@@ -173,11 +189,11 @@ def test_aux_kernels_vs_torch():
         gu = torch.randn(2, 8, ho, wo, generator=g).to(DEV)
         ur.backward(gu.to(torch.bfloat16).float())
         gx = uh.upsample_bwd(_nhwc(gu), hs, ws)
-        assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.05
+        assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.05 + 0.008 * xr.grad.abs().max().item()   # bf16 output
         src = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
         gx2 = uh.upsample_bwd(_nhwc(gu), hs, ws, relu_src=_nhwc(src), scale=2.0)
         want = (xr.grad * (src.to(torch.bfloat16).float() > 0) * 2.0).permute(0, 2, 3, 1)
-        assert (gx2.float() - want).abs().max().item() < 0.1
+        assert (gx2.float() - want).abs().max().item() < 0.1 + 0.008 * want.abs().max().item()
     # final layer
     xf = F.relu(torch.randn(2, 8, 10, 12, generator=g)).to(DEV)
     wf = torch.randn(8, generator=g).to(DEV)
