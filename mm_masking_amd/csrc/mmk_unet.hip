@@ -394,6 +394,30 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Loads / stores / waits that hipcc does not see.  In the kernels without epilogue operands every
+// vector-memory instruction of the steady-state loop is one of these, the number of instructions
+// between a tile's loads and their use is a compile-time constant, and the wait before the LDS
+// write is the exact s_waitcnt vmcnt(N) that leaves the RD-1 younger tiles in flight (hipcc's own
+// bookkeeping settles for N ~ one stage: DESIGN.md 5b).
+__device__ __forceinline__ u32x4 asm_load16(const u32x4 *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void asm_store8(void *p, unsigned long long v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void asm_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
 template <int CK, int CM, int RD, bool EPI>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
@@ -406,6 +430,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr bool MAN = !EPI;                                 // hand-counted vmcnt (see asm_load16)
+    constexpr int NST = MT * NT;                               // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
     bf16 *w_lds = in_tile + 2 * HT * WT * PK;
@@ -423,33 +449,101 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     const int nt_blk = (t_end - first + nb - 1) / nb;         // tiles of this block: first + k * nb
 
     u32x4 rin[RD][RIN];
-    // the granules this thread stages are the same for every tile: precompute their place in the tile
-    int g_dy[RIN], g_dx[RIN], g_c[RIN];
+    // Everything per-lane that does not depend on the tile is worked out once: addresses inside the
+    // loop are then "uniform tile origin (scalar unit) + 32-bit lane offset", a handful of VALU
+    // instructions per access instead of a 64-bit index computation (the full-resolution layers
+    // are bound by instruction issue, not by the matrix cores).  Offsets are in elements and fit
+    // 32 bits (the launcher checks B*H*W*C < 2^31).
+    int g_dy[RIN], g_dx[RIN], in_off[RIN];
+    bool in_x2[RIN];
 #pragma unroll
     for (int i = 0; i < RIN; ++i) {
         int g = tid + i * CONV_THREADS;
         g = g < NIN ? g : NIN - 1;
-        const int pix = g / GPP;
-        g_dy[i] = pix / WT - 1;
-        g_dx[i] = pix % WT - 1;
-        g_c[i] = (g % GPP) * 8;
+        const int pix = g / GPP, c = (g % GPP) * 8;
+        const int dy1 = pix / WT, dx1 = pix % WT;
+        g_dy[i] = dy1 - 1;
+        g_dx[i] = dx1 - 1;
+        in_x2[i] = c >= a.C1;
+        in_off[i] = in_x2[i] ? (dy1 * a.W + dx1) * a.C2 + (c - a.C1) : (dy1 * a.W + dx1) * a.C1 + c;
+    }
+    // output side: lane (m, n) owns 4 channels from c0 of pixel (2 wv + n/2, 16 (n&1) + lane%16) of the tile
+    bool o_cv[MT], o_has_src[MT], o_accm[MT];
+    bf16 *o_yb[MT];
+    const bf16 *o_sb[MT];
+    int o_C[MT], o_e0[MT], o_loff[MT][NT];
+    float o_scale[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
+        const bool firstp = c0 < a.o1.C;
+        const int cl = firstp ? c0 : c0 - a.o1.C;
+        o_cv[m] = c0 < a.COUT;
+        o_yb[m] = (firstp ? a.o1.y : a.o2.y) + cl;
+        const bf16 *sb = firstp ? a.o1.relu_src : a.o2.relu_src;
+        o_has_src[m] = sb != nullptr;
+        o_sb[m] = sb + cl;
+        o_C[m] = firstp ? a.o1.C : a.o2.C;
+        o_scale[m] = firstp ? a.o1.scale : a.o2.scale;
+        o_accm[m] = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
+        o_e0[m] = c0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o_loff[m][n] = ((2 * wv + (n >> 1)) * a.W + (n & 1) * 16 + (lane & 15)) * o_C[m];
+    }
+    int lane_pix[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) lane_pix[n] = (2 * wv + (n >> 1)) * a.W + (n & 1) * 16 + (lane & 15);
+    const float relu_lo = a.relu ? 0.f : -INFINITY;           // v = max(v, relu_lo): ReLU or identity
+    // LDS read offsets of the B fragments: per-lane part (tap of the lane's k group) per k-step; the
+    // N-tile part is an immediate
+    int b_lane[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int tap, ch;
+        kslot<CK>(ks, lane, tap, ch);
+        tap = tap > 8 ? 8 : tap;
+        b_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PK + ch;
     }
 
-#define MMK_RING_LOAD(SLOT, KK)                                                                              \
+    // ---- the block's tile walk, on the scalar unit: tile `first + k nb` is (ld_b, ld_ty, ld_tx)
+    const int adv_tx = nb % tiles_x, adv_ty = (nb / tiles_x) % tiles_y, adv_b = nb / tpi;
+    int ld_b = first / tpi, ld_ty = (first % tpi) / tiles_x, ld_tx = first % tiles_x;
+    int ld_left = nt_blk - 1;                                  // advances still allowed (then the walk parks)
+    int s_pix0[RD], s_ty0[RD], s_tx0[RD];                      // first pixel / origin of the tile in each ring slot
+    int cur_pix0 = 0, cur_ty0 = 0, cur_tx0 = 0;                // ... of the tile in LDS
+
+#define MMK_RING_LOAD(SLOT)                                                                                  \
     {                                                                                                        \
-        int kk_ = (KK);                                                                                      \
-        kk_ = kk_ < nt_blk ? kk_ : nt_blk - 1;                                                               \
-        const int t_ = first + kk_ * nb;                                                                     \
-        const int b_ = t_ / tpi, tr_ = t_ - b_ * tpi;                                                        \
-        const int ty_ = tr_ / tiles_x;                                                                       \
-        const int tx0_ = (tr_ - ty_ * tiles_x) * TW, ty0_ = ty_ * TH;                                        \
+        const int ty0_ = ld_ty * TH, tx0_ = ld_tx * TW;                                                      \
+        const int pix0_ = (ld_b * a.H + ty0_) * a.W + tx0_;                                                  \
+        s_pix0[SLOT] = pix0_; s_ty0[SLOT] = ty0_; s_tx0[SLOT] = tx0_;                                        \
+        const long org_ = (long)pix0_ - a.W - 1;                       /* halo origin pixel */               \
+        const bf16 *base1_ = a.x1 + org_ * a.C1, *base2_ = a.x2 + org_ * a.C2;                               \
         _Pragma("unroll") for (int i = 0; i < RIN; ++i) {                                                    \
-            const int yy = ty0_ + g_dy[i], xx = tx0_ + g_dx[i];                                              \
-            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;                                      \
-            const size_t p_ = ((size_t)b_ * a.H + yy) * a.W + xx;                                            \
-            const bf16 *src = (g_c[i] < a.C1) ? a.x1 + p_ * a.C1 + g_c[i] : a.x2 + p_ * a.C2 + (g_c[i] - a.C1); \
+            const bool ok = (unsigned)(ty0_ + g_dy[i]) < (unsigned)a.H && (unsigned)(tx0_ + g_dx[i]) < (unsigned)a.W; \
+            const bf16 *src = (in_x2[i] ? base2_ : base1_) + in_off[i];                                      \
             const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16;                         \
-            rin[SLOT][i] = *sp;                                                                              \
+            if constexpr (MAN) rin[SLOT][i] = asm_load16(sp);                                                \
+            else rin[SLOT][i] = *sp;                                                                         \
+        }                                                                                                    \
+        /* next tile of the walk (parks on the block's last tile: the ring keeps re-loading it) */           \
+        const bool adv_ = ld_left > 0;                                                                       \
+        ld_left -= adv_ ? 1 : 0;                                                                             \
+        int ntx_ = ld_tx + adv_tx;                                                                           \
+        const int cx_ = ntx_ >= tiles_x ? 1 : 0;                                                             \
+        ntx_ -= cx_ ? tiles_x : 0;                                                                           \
+        int nty_ = ld_ty + adv_ty + cx_;                                                                     \
+        const int cy_ = nty_ >= tiles_y ? 1 : 0;                                                             \
+        nty_ -= cy_ ? tiles_y : 0;                                                                           \
+        ld_tx = adv_ ? ntx_ : ld_tx;                                                                         \
+        ld_ty = adv_ ? nty_ : ld_ty;                                                                         \
+        ld_b = adv_ ? ld_b + adv_b + cy_ : ld_b;                                                             \
+    }
+#define MMK_RING_SINKS()                                                                                     \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NST; ++i) {                                                    \
+            if constexpr (MAN) asm_store8(g_sink16, 0ull);                                                   \
+            else reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull;                                 \
         }                                                                                                    \
     }
 #define MMK_RING_STORE(SLOT, BUF)                                                                            \
@@ -470,16 +564,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
             if (g < NW) reinterpret_cast<u32x4 *>(w_lds)[g] = wsrc[g];
         }
     }
-    MMK_RING_LOAD(0, 0);
-    MMK_RING_LOAD(1, 1);
-    if constexpr (RD > 2) MMK_RING_LOAD(2, 2);
-    MMK_RING_STORE(0, 0);
-    MMK_RING_LOAD(0, RD);
-    // as many (sink) stores as one epilogue issues: the first stage then enters with the same
-    // load/store queue shape as every later one, and its vmcnt wait is the steady-state one
-#pragma unroll
-    for (int i = 0; i < MT * NT; ++i) reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull;
-
     const DropoutParams dp = dropout_params(a.drop_p);
     // per-lane output channel bookkeeping (does not depend on the tile)
     float bs[MT][4];
@@ -488,8 +572,29 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
         const int c0 = group * CM + m * 16 + (lane >> 4) * 4;
         const float *bp = (a.bias && c0 < a.COUT) ? a.bias + c0 : reinterpret_cast<const float *>(&g_zero16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bs[m][r] = bp[r];
+        for (int r = 0; r < 4; ++r) {
+            bs[m][r] = bp[r];
+            // consumed here: a load still pending at the loop header would make every stage wait for
+            // "everything older than the bias", i.e. for the whole ring
+            asm volatile("" : "+v"(bs[m][r]));
+        }
     }
+
+    // Fill the ring.  Sink stores stand in for the epilogues that have not run yet, so that the
+    // first stage meets the same load/store queue as every later one:
+    //   [tile k+1] NST stores [tile k+2] NST stores ... [tile k+RD] NST stores
+    MMK_RING_LOAD(0);
+    MMK_RING_LOAD(1);
+    MMK_RING_SINKS();
+    if constexpr (RD > 2) {
+        MMK_RING_LOAD(2);
+        MMK_RING_SINKS();
+    }
+    if constexpr (MAN) asm_wait_vmcnt<(RD - 1) * (RIN + NST)>();
+    cur_pix0 = s_pix0[0]; cur_ty0 = s_ty0[0]; cur_tx0 = s_tx0[0];
+    MMK_RING_STORE(0, 0);
+    MMK_RING_LOAD(0);
+    MMK_RING_SINKS();
 
     // The first round is peeled off the loop: hipcc merges the load/store queue state of every edge
     // into the loop header by its minimum, and the prologue's short queue would otherwise turn the
@@ -812,7 +917,8 @@ int dispatch_conv(const ConvArgs &a, hipStream_t st)
 {
     if (conv_is_deep(a.CIN, a.COUT)) return dispatch_conv_deep(a, st);
     const int CK = conv_ck(a.CIN), CM = conv_cm(a.CIN, a.COUT);
-    if (a.CIN == CK && CM <= 32 && use_ring_kernels()) {
+    const bool fits32 = (size_t)a.B * a.H * a.W * (size_t)std::max(a.CIN, a.COUT) < ((size_t)1 << 31);
+    if (a.CIN == CK && CM <= 32 && fits32 && use_ring_kernels()) {
 #define MMK_RING_CASE(K, M) if (CK == K && CM == M) return launch_conv_ring_epi<K, M>(a, st)
         MMK_RING_CASE(8, 16); MMK_RING_CASE(8, 32); MMK_RING_CASE(16, 16); MMK_RING_CASE(16, 32);
         MMK_RING_CASE(32, 16); MMK_RING_CASE(32, 32);

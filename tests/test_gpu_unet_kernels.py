@@ -43,6 +43,29 @@ def test_conv3x3_forward(cin, cout, H, W):
     assert (y2.float() - ref2).abs().max().item() < 0.03
 
 
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 16), (16, 8), (32, 32), (8, 16), (64, 64)])
+def test_conv3x3_many_tiles_per_block(cin, cout):
+    """Large enough that every persistent block walks a dozen tiles: the steady state of the
+    register ring (hand-counted s_waitcnt in the kernels without epilogue operands), both the
+    plain forward form and the data-gradient form with ReLU source + accumulation."""
+    B, H, W = 6, 512, 512
+    x = _rand_nhwc(B, H, W, cin, 17 * cin + cout)
+    g = torch.Generator().manual_seed(cin + cout)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    wp = uh.pack_weights(w)
+    ref = _ref_conv(x, w, b, True)
+    y = uh.conv3x3(x, wp, cout, bias=b, relu=True)
+    assert (y.float() - ref).abs().max().item() < 0.03
+    del y
+    src = _rand_nhwc(B, H, W, cout, 99)
+    base = _rand_nhwc(B, H, W, cout, 98)
+    ref2 = _ref_conv(x, w, None, False)
+    want = base.float() + torch.where(src.float() > 0, ref2 * 1.5, torch.zeros_like(ref2))
+    o = uh.conv3x3(x, wp, cout, out=base.clone(), accumulate=True, relu_src=src, scale=1.5)
+    assert (o.float() - want).abs().max().item() < 0.06
+
+
 def test_conv3x3_concat_split_accumulate_relu_src():
     B, H, W = 2, 24, 40
     xa, xb = _rand_nhwc(B, H, W, 8, 1), _rand_nhwc(B, H, W, 8, 2)
