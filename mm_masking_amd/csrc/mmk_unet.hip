@@ -982,24 +982,27 @@ struct WgradArgs {
     int B, H, W, CIN, COUT;
 };
 
-template <int CK, int CM>
+template <int CK, int CM, bool G8>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
+    // G8: the gradient tensor has 8 channels (COUT = 8, CM = 16): its LDS pitch is 8 elements
     constexpr int MT = CM / 16;
     constexpr int NTT = (CK >= 16) ? 9 * (CK / 16) : 5;  // n-tiles of 16 (tap, ci) columns
     constexpr int NTW = (NTT + 3) / 4;                    // per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PK = lds_pitch(CK);
+    constexpr int GCOLS = G8 ? 8 : CM;                    // channels of the g tile
+    constexpr int PG = lds_pitch(GCOLS);
     bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // HT*WT*PK (+ pad)
     bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // TH*TW*PG (+ pad)
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: branches on it are scalar
     const int chunk = blockIdx.y, group = blockIdx.z;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int total_tiles = tiles_x * tiles_y * a.B;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
     const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-    const int gcols = (a.COUT < CM) ? a.COUT : CM;   // valid columns of the g tile (COUT = 8 -> 8)
-    const int PG = lds_pitch(gcols);
 
     f32x4 acc[MT][NTW];
     f32x4 accb[MT];
@@ -1013,8 +1016,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
 
-    // per-lane LDS byte offsets that do not depend on the tile
-    unsigned b_off[NTW];
+    // per-lane LDS addresses that do not depend on the tile row (the row goes into the read's
+    // immediate offset)
+    unsigned b_ad[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         const int nt = wv + 4 * n;
@@ -1028,62 +1032,63 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         }
         tap = tap > 8 ? 8 : tap;
         const int ty = tap / 3, tx = tap % 3;
-        b_off[n] = (unsigned)((((ty * WT) + 8 * g4 + q + tx) * PK + col) * 2);
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 8 * g4 + q + tx) * PK + col) * 2);
     }
-    const unsigned xbase = lds_addr(x_tile), gbase = lds_addr(g_tile);
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((8 * g4 + q) * PG + 4 * pp) * 2);
 
-    // register prefetch of the next tile's operands while the current one is consumed
+    // register prefetch of the next tile's operands while the current one is consumed; every load
+    // is unconditional (out-of-image granules read the zero word)
     constexpr int GPP = CK / 8;
     constexpr int NIN = HT * WT * GPP;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int GPGM = CM / 8;                                   // upper bound of granules per g pixel
-    constexpr int RG = (TH * TW * GPGM + CONV_THREADS - 1) / CONV_THREADS;
-    const int GPG = gcols / 8;
-    const int NG = TH * TW * GPG;
-    uint4 rin[RIN], rg[RG];
+    constexpr int GPG = GCOLS / 8;
+    constexpr int NG = TH * TW * GPG;
+    constexpr int RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
+    u32x4 rin[RIN], rg[RG];
     auto load_tile = [&](int t) {
-        const int b = t / (tiles_x * tiles_y);
-        const int tr = t % (tiles_x * tiles_y);
-        const int tx0 = (tr % tiles_x) * TW, ty0 = (tr / tiles_x) * TH;
+        int tv = tid;                       // opaque: per-granule offsets are recomputed, not kept live
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
 #pragma unroll
         for (int i = 0; i < RIN; ++i) {
-            const int gi = tid + i * CONV_THREADS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gi < NIN) {
-                const int pix = gi / GPP, gc = gi % GPP;
-                const int yy = ty0 + pix / WT - 1, xx = tx0 + pix % WT - 1;
-                const int c = chunk * CK + gc * 8;
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                    const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                    if (c < a.C1) v = *reinterpret_cast<const uint4 *>(a.x1 + p * a.C1 + c);
-                    else v = *reinterpret_cast<const uint4 *>(a.x2 + p * a.C2 + (c - a.C1));
-                }
-            }
-            rin[i] = v;
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NIN ? gi : NIN - 1;
+            const int pix = gi / GPP, gc = gi % GPP;
+            const int dy = pix / WT - 1, dx = pix % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            const int c = chunk * CK + gc * 8;
+            const int p = pix0 + dy * a.W + dx;
+            const bf16 *src = (c < a.C1) ? a.x1 + ((long)p * a.C1 + c) : a.x2 + ((long)p * a.C2 + (c - a.C1));
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16;
+            rin[i] = *sp;
         }
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
-            const int gi = tid + i * CONV_THREADS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gi < NG) {
-                const int pix = gi / GPG, gc = gi % GPG;
-                const int yy = ty0 + pix / TW, xx = tx0 + pix % TW;
-                if (yy < a.H && xx < a.W)
-                    v = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * a.COUT + group * CM + gc * 8);
-            }
-            rg[i] = v;
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NG ? gi : NG - 1;
+            const int pix = gi / GPG, gc = gi % GPG;
+            const int dy = pix / TW, dx = pix % TW;
+            const bool ok = ty0 + dy < a.H && tx0 + dx < a.W;
+            const int p = pix0 + dy * a.W + dx;
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(a.g + ((long)p * a.COUT + group * CM + gc * 8)) : &g_zero16;
+            rg[i] = *sp;
         }
     };
     auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
 #pragma unroll
         for (int i = 0; i < RIN; ++i) {
-            const int gi = tid + i * CONV_THREADS;
-            if (gi < NIN) *reinterpret_cast<uint4 *>(x_tile + (size_t)(gi / GPP) * PK + (gi % GPP) * 8) = rin[i];
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NIN) *reinterpret_cast<u32x4 *>(x_tile + (size_t)(gi / GPP) * PK + (gi % GPP) * 8) = rin[i];
         }
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
-            const int gi = tid + i * CONV_THREADS;
-            if (gi < NG) *reinterpret_cast<uint4 *>(g_tile + (size_t)(gi / GPG) * PG + (gi % GPG) * 8) = rg[i];
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NG) *reinterpret_cast<u32x4 *>(g_tile + (size_t)(gi / GPG) * PG + (gi % GPG) * 8) = rg[i];
         }
     };
 
@@ -1092,49 +1097,55 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (t + (int)gridDim.x < total_tiles) load_tile(t + gridDim.x);
-        // fragments of tile row r+1 are fetched from LDS while the matrix cores consume row r
-        i32x2 fa[2][2 * MT], fb[2][2 * NTW];
-        auto issue_reads = [&](int r, i32x2 *ra, i32x2 *rb) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const unsigned ad = gbase + (unsigned)(((r * TW + 8 * g4 + q) * PG + m * 16 + 4 * pp) * 2);
-                ra[2 * m] = tr_read(ad);
-                ra[2 * m + 1] = tr_read(ad + (unsigned)(4 * PG * 2));
-            }
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const unsigned ad = xbase + b_off[n] + (unsigned)(r * WT * PK * 2);
-                rb[2 * n] = tr_read(ad);
-                rb[2 * n + 1] = tr_read(ad + (unsigned)(4 * PK * 2));
-            }
-        };
-        auto consume = [&](const i32x2 *ra, const i32x2 *rb) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const bf16x8 af = frag_from(ra[2 * m], ra[2 * m + 1]);
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    if (wv + 4 * n < NTT)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(rb[2 * n], rb[2 * n + 1]), acc[m][n], 0, 0, 0);
-                }
-                if (wv == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0);
-            }
-        };
-        issue_reads(0, fa[0], fb[0]);
-#pragma unroll 1
-        for (int r = 0; r < TH; r += 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            issue_reads(r + 1, fa[1], fb[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(fa[0], fb[0]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (r + 2 < TH) issue_reads(r + 2, fa[0], fb[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(fa[1], fb[1]);
+        {
+            const int nt = t + (int)gridDim.x;
+            load_tile(nt < total_tiles ? nt : t);
         }
+        // fragments of tile row r+1 are fetched from LDS while the matrix cores consume row r; the
+        // rows are unrolled so that every read carries its row offset as an immediate
+        i32x2 fa[2][2 * MT], fb[2][2 * NTW];
+#define WG_ISSUE(R, BUF)                                                                                 \
+    {                                                                                                    \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                 \
+            fa[BUF][2 * m] = (m == 0) ? tr_read_o<((R) * TW * PG) * 2>(g_ad)                             \
+                           : (m == 1) ? tr_read_o<((R) * TW * PG + 16) * 2>(g_ad)                        \
+                           : (m == 2) ? tr_read_o<((R) * TW * PG + 32) * 2>(g_ad)                        \
+                                      : tr_read_o<((R) * TW * PG + 48) * 2>(g_ad);                       \
+            fa[BUF][2 * m + 1] = (m == 0) ? tr_read_o<((R) * TW * PG + 4 * PG) * 2>(g_ad)                \
+                               : (m == 1) ? tr_read_o<((R) * TW * PG + 16 + 4 * PG) * 2>(g_ad)           \
+                               : (m == 2) ? tr_read_o<((R) * TW * PG + 32 + 4 * PG) * 2>(g_ad)           \
+                                          : tr_read_o<((R) * TW * PG + 48 + 4 * PG) * 2>(g_ad);          \
+        }                                                                                                \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                                \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                                    \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 4 * PK) * 2>(b_ad[n]);                       \
+        }                                                                                                \
+    }
+#define WG_CONSUME(BUF)                                                                                  \
+    {                                                                                                    \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                 \
+            const bf16x8 af = frag_from(fa[BUF][2 * m], fa[BUF][2 * m + 1]);                             \
+            /* unconditional (a padding n-tile or a bias sum nobody flushes costs an MFMA; a branch  */ \
+            /* here makes hipcc shuttle every accumulator between AGPRs and VGPRs)                    */ \
+            _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[m][n], 0, 0, 0); \
+            accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0);               \
+        }                                                                                                \
+    }
+#define WG_STEP(R)                                                                                       \
+    {                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((R) + 1 < TH) WG_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        WG_CONSUME((R) & 1);                                                                             \
+    }
+        WG_ISSUE(0, 0);
+        WG_STEP(0) WG_STEP(1) WG_STEP(2) WG_STEP(3) WG_STEP(4) WG_STEP(5) WG_STEP(6) WG_STEP(7)
+        static_assert(TH == 8, "WG_STEP expansion above covers 8 tile rows");
+#undef WG_STEP
+#undef WG_CONSUME
+#undef WG_ISSUE
     }
 
     // ---- one atomic pass per block
@@ -1163,28 +1174,28 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     }
 }
 
-template <int CK, int CM>
+template <int CK, int CM, bool G8>
 int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
-    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(CM)) * sizeof(bf16);
-    if (smem > 64 * 1024) {
-        static bool attr_set[64] = {};   // per template instantiation and device
-        int dev = 0;
-        MMK_CHECK_HIP(hipGetDevice(&dev));
-        if (!attr_set[dev & 63]) {
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set[dev & 63] = true;
-        }
+    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(G8 ? 8 : CM)) * sizeof(bf16);
+    static int per_cu[64] = {};      // resident blocks per CU (registers / LDS), per device
+    int dev = 0;
+    MMK_CHECK_HIP(hipGetDevice(&dev));
+    if (per_cu[dev & 63] == 0) {
+        if (smem > 64 * 1024)
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM, G8>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nblk = 0;
+        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_wgrad_kernel<CK, CM, G8>, CONV_THREADS, smem));
+        per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
     const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
-    // persistent grid sized to what the LDS footprint lets the 256 CUs hold: every extra block
-    // costs one more fp32 atomic pass over its dW slice (147 KB for a 64x64-channel slice)
-    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
-    per_cu = per_cu < 1 ? 1 : per_cu;
-    int spatial = std::min(256 * per_cu, 768) / (chunks * groups);
+    // persistent grid sized to what the 256 CUs hold at once: every extra block costs one more
+    // fp32 atomic pass over its dW slice
+    int spatial = (256 * per_cu[dev & 63]) / (chunks * groups);
     spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CK, CM>), dim3(spatial, chunks, groups), dim3(CONV_THREADS), smem, st, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CK, CM, G8>), dim3(spatial, chunks, groups), dim3(CONV_THREADS), smem, st, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -1206,7 +1217,8 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
     bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // (HT*WT + 8) * PK
     bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // (TH*TW + 8) * PG
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: branches on it are scalar
     const int wm = wv >> 2, wc = wv & 3;
     const int chunk = blockIdx.y, group = blockIdx.z;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
                     const bf16x8 af = frag_from(fa[r % 3][m][0], fa[r % 3][m][1]);                       \
                     _Pragma("unroll") for (int tx = 0; tx < 3; ++tx)                                     \
                         acc[ty][tx][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[tx], acc[ty][tx][m], 0, 0, 0); \
-                    if (ty == 0 && wc == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0); \
+                    if (ty == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0); /* every wave: no branch */ \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
@@ -1394,7 +1406,7 @@ int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
     }
     if (deep && a.CIN % 64 == 0 && a.COUT % 64 == 0 && a.C1 % 64 == 0) return launch_wgrad_deep(a, st);
     const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
-#define MMK_WG_CASE(K, M) if (CK == K && CM == M) return launch_wgrad<K, M>(a, st)
+#define MMK_WG_CASE(K, M) if (CK == K && CM == M) return (M == 16 && a.COUT == 8) ? launch_wgrad<K, M, (M == 16)>(a, st) : launch_wgrad<K, M, false>(a, st)
     MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);
     MMK_WG_CASE(16, 16); MMK_WG_CASE(16, 32); MMK_WG_CASE(16, 64);
     MMK_WG_CASE(32, 16); MMK_WG_CASE(32, 32); MMK_WG_CASE(32, 64);
