@@ -196,6 +196,11 @@ typedef struct {
 size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t transposed);
 int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t cin, int32_t transposed,
                              void *packed, void *stream);
+/* n layers in one launch: W[i] fp32 (cout[i],cin[i],3,3) -> packed[i] (mmk_conv3x3_packed_elems elements
+ * each); replaces the per-layer .to(bf16) casts autocast performs on every nn.Conv2d call
+ * (icp_weight_policy.py:104-125 run under torch.autocast). */
+int mmk_conv3x3_pack_weights_batch(int32_t n, const float *const *W, const int32_t *cout, const int32_t *cin,
+                                   int32_t transposed, void *const *packed, void *stream);
 int mmk_conv3x3(const mmk_conv_desc *d, void *stream);
 /* Weight + bias gradient of the same convolution (autograd of nn.Conv2d,
  * train_icp_weights.py:51): dWt[tap][cout][cin] += sum_pixels g * shifted input, db[cout] += sum g
@@ -205,6 +210,9 @@ int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, co
                       int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream);
 int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
                              void *stream);
+/* n layers in one launch (no accumulation): dW[i] (cout,cin,3,3) = dWt[i] (9,cout,cin) */
+int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *dWt, const int32_t *cout, const int32_t *cin,
+                                   float *const *dW, void *stream);
 
 /* First conv of the network (encoder.0.0): fp32 NCHW input (B,cin,H,W), cin = 1..4
  * (fft | cfar | range channels, icp_weight_policy.py:84), W[8][cin][3][3], + bias + ReLU ->

@@ -68,11 +68,9 @@ __device__ __forceinline__ void kslot(int s, int l, int &tap, int &ch)
 // Weight packing: fp32 master weights W[COUT][CIN][3][3] -> bf16 in MFMA A-fragment order
 // [group][chunk][kstep][mtile][lane][8].  transposed = 1 packs the data-gradient operator
 // (out channels = CIN, in channels = COUT, taps flipped).
-__global__ void pack_conv_weights_kernel(const float *__restrict__ W, int COUT, int CIN, int transposed,
-                                         bf16 *__restrict__ out, int total)
+__device__ __forceinline__ void pack_conv_weight_elem(const float *__restrict__ W, int COUT, int CIN, int transposed,
+                                                      bf16 *__restrict__ out, int e)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
     const int co_n = transposed ? CIN : COUT;   // channels produced by the packed operator
     const int ci_n = transposed ? COUT : CIN;   // channels consumed
     const int CK = conv_ck(ci_n), CM = conv_cm(ci_n, co_n);
@@ -104,6 +102,32 @@ __global__ void pack_conv_weights_kernel(const float *__restrict__ W, int COUT, 
         else v = W[((size_t)co * CIN + ci) * 9 + tap];
     }
     out[e] = (bf16)v;
+}
+
+__global__ void pack_conv_weights_kernel(const float *__restrict__ W, int COUT, int CIN, int transposed,
+                                         bf16 *__restrict__ out, int total)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    pack_conv_weight_elem(W, COUT, CIN, transposed, out, e);
+}
+
+// All layers of a network in one launch (blockIdx.y = layer): 42 five-microsecond launches per
+// training step otherwise.
+constexpr int PACK_BATCH_MAX = 32;
+struct PackBatch {
+    const float *W[PACK_BATCH_MAX];
+    bf16 *out[PACK_BATCH_MAX];
+    int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX], total[PACK_BATCH_MAX];
+    int transposed;
+};
+
+__global__ void pack_conv_weights_batch_kernel(const PackBatch pb)
+{
+    const int l = blockIdx.y;
+    const int total = pb.total[l];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
+        pack_conv_weight_elem(pb.W[l], pb.cout[l], pb.cin[l], pb.transposed, pb.out[l], e);
 }
 
 struct ConvOutPart {
@@ -1427,6 +1451,25 @@ __global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int
     dW[e] = accumulate ? dW[e] + v : v;
 }
 
+struct UnpackBatch {
+    const float *dWt[PACK_BATCH_MAX];
+    float *dW[PACK_BATCH_MAX];
+    int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX];
+};
+
+__global__ void unpack_wgrad_batch_kernel(const UnpackBatch ub)
+{
+    const int l = blockIdx.y;
+    const int COUT = ub.cout[l], CIN = ub.cin[l];
+    const int total = COUT * CIN * 9;
+    const float *__restrict__ src = ub.dWt[l];
+    float *__restrict__ dst = ub.dW[l];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+        dst[e] = src[((size_t)tap * COUT + co) * CIN + ci];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // First layer: fp32 NCHW input with 1..4 channels -> 8 channels NHWC bf16 (+bias, ReLU).
 // 72..288 FMAs per pixel: plain VALU, HBM-bound.
@@ -1889,6 +1932,32 @@ extern "C" int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t ci
     return MMK_OK;
 }
 
+extern "C" int mmk_conv3x3_pack_weights_batch(int32_t n, const float *const *W, const int32_t *cout, const int32_t *cin,
+                                              int32_t transposed, void *const *packed, void *stream)
+{
+    MMK_REQUIRE(n >= 1 && W && cout && cin && packed, "mmk_conv3x3_pack_weights_batch: bad argument");
+    for (int base = 0; base < n; base += PACK_BATCH_MAX) {
+        PackBatch pb;
+        const int m = std::min(PACK_BATCH_MAX, n - base);
+        size_t most = 0;
+        for (int i = 0; i < PACK_BATCH_MAX; ++i) {
+            const int k = base + (i < m ? i : 0);
+            MMK_REQUIRE(W[k] && packed[k], "mmk_conv3x3_pack_weights_batch: NULL pointer (layer %d)", k);
+            const size_t total = mmk_conv3x3_packed_elems(cout[k], cin[k], transposed);
+            MMK_REQUIRE(total > 0 && total < ((size_t)1 << 31), "mmk_conv3x3_pack_weights_batch: unsupported channel counts %d -> %d",
+                        cin[k], cout[k]);
+            pb.W[i] = W[k]; pb.out[i] = (bf16 *)packed[k]; pb.cout[i] = cout[k]; pb.cin[i] = cin[k];
+            pb.total[i] = (int)total;
+            most = std::max(most, total);
+        }
+        pb.transposed = transposed;
+        const unsigned bx = (unsigned)std::min<size_t>((most + 255) / 256, 256);
+        hipLaunchKernelGGL(pack_conv_weights_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, pb);
+        MMK_LAUNCH_CHECK();
+    }
+    return MMK_OK;
+}
+
 extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
 {
     MMK_REQUIRE(d != nullptr, "mmk_conv3x3: NULL descriptor");
@@ -1931,6 +2000,27 @@ extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t 
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dWt, cout, cin,
                        accumulate, dW);
     MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *dWt, const int32_t *cout, const int32_t *cin,
+                                              float *const *dW, void *stream)
+{
+    MMK_REQUIRE(n >= 1 && dWt && cout && cin && dW, "mmk_conv3x3_wgrad_unpack_batch: bad argument");
+    for (int base = 0; base < n; base += PACK_BATCH_MAX) {
+        UnpackBatch ub;
+        const int m = std::min(PACK_BATCH_MAX, n - base);
+        int most = 0;
+        for (int i = 0; i < PACK_BATCH_MAX; ++i) {
+            const int k = base + (i < m ? i : 0);
+            MMK_REQUIRE(dWt[k] && dW[k] && cout[k] >= 1 && cin[k] >= 1, "mmk_conv3x3_wgrad_unpack_batch: bad layer %d", k);
+            ub.dWt[i] = dWt[k]; ub.dW[i] = dW[k]; ub.cout[i] = cout[k]; ub.cin[i] = cin[k];
+            most = std::max(most, cout[k] * cin[k] * 9);
+        }
+        const unsigned bx = (unsigned)std::min((most + 255) / 256, 256);
+        hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
+        MMK_LAUNCH_CHECK();
+    }
     return MMK_OK;
 }
 

@@ -32,6 +32,28 @@ def pack_weights(w, transposed=False):
     return out
 
 
+def pack_weights_batch(ws, transposed=False):
+    """Pack a list of fp32 (COUT,CIN,3,3) weights in one launch -> list of packed bf16 views of one buffer."""
+    L = _lib.lib()
+    n = len(ws)
+    tr = 1 if transposed else 0
+    sizes = [L.mmk_conv3x3_packed_elems(w.shape[0], w.shape[1], tr) for w in ws]
+    if any(sz == 0 for sz in sizes):
+        raise _lib.MmkError("unsupported conv channel counts in pack_weights_batch")
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + (sz + 127) // 128 * 128)
+    buf = torch.empty(offs[-1], dtype=BF16, device=ws[0].device)
+    base = buf.data_ptr()
+    wsrc = [w.detach().float().contiguous() for w in ws]
+    Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in wsrc])
+    Op = (ctypes.c_void_p * n)(*[base + 2 * o for o in offs[:-1]])
+    co = (ctypes.c_int32 * n)(*[w.shape[0] for w in ws])
+    ci = (ctypes.c_int32 * n)(*[w.shape[1] for w in ws])
+    _lib.check(L.mmk_conv3x3_pack_weights_batch(n, Wp, co, ci, tr, Op, _lib.stream_ptr(ws[0].device)))
+    return [buf[offs[i]:offs[i] + sizes[i]] for i in range(n)]
+
+
 def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0, out=None, out2=None, split=None,
             relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False):
     """3x3 / pad 1 convolution on NHWC bf16.  input = concat(x1, x2); output channels
@@ -80,6 +102,23 @@ def dropout_scale(p):
     (csrc/mmk_unet.hip: dropout_params), and the scale is the exact inverse of that keep rate."""
     thr = int(float(p) * 65536.0 + 0.5)
     return 65536.0 / (65536 - thr) if thr else 1.0
+
+
+def wgrad_unpack_batch(dWts):
+    """[(9,cout,cin), ...] -> [(cout,cin,3,3), ...] (views of one buffer) in one launch."""
+    n = len(dWts)
+    sizes = [d.numel() for d in dWts]
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + (sz + 3) // 4 * 4)
+    buf = torch.empty(offs[-1], dtype=torch.float32, device=dWts[0].device)
+    base = buf.data_ptr()
+    Sp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dWts])
+    Op = (ctypes.c_void_p * n)(*[base + 4 * o for o in offs[:-1]])
+    co = (ctypes.c_int32 * n)(*[d.shape[1] for d in dWts])
+    ci = (ctypes.c_int32 * n)(*[d.shape[2] for d in dWts])
+    _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack_batch(n, Sp, co, ci, Op, _lib.stream_ptr(dWts[0].device)))
+    return [buf[offs[i]:offs[i] + sizes[i]].view(dWts[i].shape[1], dWts[i].shape[2], 3, 3) for i in range(n)]
 
 
 # ----------------------------------------------------------------------------- small wrappers
@@ -167,11 +206,9 @@ class _UNet(torch.autograd.Function):
             ctr[0] += 1
             return ctr[0]
 
-        packs = {}
+        packs = dict(zip(range(1, 22), pack_weights_batch([wb(k)[0] for k in range(1, 22)])))
 
         def pk(k):
-            if k not in packs:
-                packs[k] = pack_weights(wb(k)[0])
             return packs[k]
 
         saved = {}
@@ -233,11 +270,9 @@ class _UNet(torch.autograd.Function):
         def W(k):
             return P[2 * k]
 
-        packs_t = {}
+        packs_t = dict(zip(range(1, 22), pack_weights_batch([W(k) for k in range(1, 22)], transposed=True)))
 
         def pkt(k):
-            if k not in packs_t:
-                packs_t[k] = pack_weights(W(k), transposed=True)
             return packs_t[k]
 
         # one zero-filled fp32 buffer for every gradient accumulator (one fill instead of ~45)
@@ -331,8 +366,8 @@ class _UNet(torch.autograd.Function):
         _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0), _sp(dev)))
         # ---- assemble parameter gradients in input order
         out = [g_w0, g_b0]
-        for k in range(1, 22):
-            out += [wgrad_unpack(dWt[k]), dB[k]]
+        for k, gw in zip(range(1, 22), wgrad_unpack_batch([dWt[k] for k in range(1, 22)])):
+            out += [gw, dB[k]]
         out += [g_fw.reshape(1, 8, 1, 1), g_fb]
         out = [g.to(p.dtype) for g, p in zip(out, P)]
         return (None, None, None, None) + tuple(out)

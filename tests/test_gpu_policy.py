@@ -197,11 +197,15 @@ def test_hip_unet_with_cfar_and_range_inputs():
     over = {"cfar_input": True, "range_input": True, "normalize": ["standardize"]}
     torch.manual_seed(21)
     mh = LearnICPWeightPolicy(_params(**over)).to(DEV)
-    mt = LearnICPWeightPolicy(_params(amp_dtype=torch.float32, unet_backend="torch", **over)).to(DEV)
-    mt.load_state_dict(mh.state_dict())
+    # the fp32 reference runs on the host: this test is about the hand-written first-layer kernels, and
+    # MIOpen's search over solvers for this odd 3-channel 96x96 problem has aborted the process on a
+    # fresh box more than once (nothing of ours is on that call stack)
+    cpu = torch.device("cpu")
+    mt = LearnICPWeightPolicy(dict(_params(amp_dtype=torch.float32, unet_backend="torch", **over), device=cpu))
+    mt.load_state_dict({k: v.cpu() for k, v in mh.state_dict().items()})
     H = 96
     mh.range_mask = mh.range_mask[:H, :H].contiguous()
-    mt.range_mask = mt.range_mask[:H, :H].contiguous()
+    mt.range_mask = mt.range_mask[:H, :H].contiguous().cpu()
     g = torch.Generator().manual_seed(3)
     x = torch.rand(2, H, H, generator=g)
     c = (torch.rand(2, H, H, generator=g) > 0.9).float()
@@ -209,11 +213,11 @@ def test_hip_unet_with_cfar_and_range_inputs():
     mh.train(), mt.train()
     a = mh(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
     b = mt(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
-    assert (a - b).abs().max().item() < 5e-3
-    gsel = torch.randn(2, H, H, generator=g).to(DEV)
-    (a * gsel).sum().backward()
+    assert (a.cpu() - b).abs().max().item() < 5e-3
+    gsel = torch.randn(2, H, H, generator=g)
+    (a * gsel.to(DEV)).sum().backward()
     (b * gsel).sum().backward()
-    ga, gb = mh.encoder[0][0].weight.grad, mt.encoder[0][0].weight.grad
+    ga, gb = mh.encoder[0][0].weight.grad.cpu(), mt.encoder[0][0].weight.grad
     assert ga.shape == (8, 3, 3, 3)
     assert torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item() > 0.9
 
