@@ -1004,6 +1004,8 @@ struct WgradArgs {
     float *dWt;      // [9][COUT][CIN]
     float *db;       // [COUT] or null
     int B, H, W, CIN, COUT;
+    float *partials; // optional [gridDim.x][9][COUT][CIN]: per-block partial sums instead of atomics into dWt
+    int acc_partials;   // add to what `partials` holds (second application of shared weights)
 };
 
 template <int CK, int CM, bool G8>
@@ -1392,15 +1394,49 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
         for (int rr = 0; rr < 4; ++rr) {
             const int co = group * CM + (wm * 2 + m) * 16 + g4 * 4 + rr;
             const int ci = chunk * CK + wc * 16 + i16;
+            if (a.partials) {
+                // plain stores into this block's own slice (summed by the unpack kernel): float atomics
+                // run at ~1.3 TB/s and 256 blocks x 147 KB of them cost 30-35 us per launch
+                float *ps = a.partials + (size_t)blockIdx.x * 9 * a.COUT * a.CIN + (size_t)co * a.CIN + ci;
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
+                for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx)
-                    atomicAdd(&a.dWt[((size_t)(ty * 3 + tx) * a.COUT + co) * a.CIN + ci], acc[ty][tx][m][rr]);
+                    for (int tx = 0; tx < 3; ++tx) {
+                        float *d = ps + (size_t)(ty * 3 + tx) * a.COUT * a.CIN;
+                        *d = a.acc_partials ? *d + acc[ty][tx][m][rr] : acc[ty][tx][m][rr];
+                    }
+            } else {
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+                        atomicAdd(&a.dWt[((size_t)(ty * 3 + tx) * a.COUT + co) * a.CIN + ci], acc[ty][tx][m][rr]);
+            }
             if (a.db && wc == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
         }
     }
 }
+
+// blocks along the pixel tiles (= partial slices of dW) of the 8-wave weight-gradient kernel
+int wgrad_deep_slices(int cout, int cin, int B, int H, int W)
+{
+    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int chunks = cin / 64, groups = cout / 64;
+    int spatial = 256 / (chunks * groups);            // one 8-wave block per CU
+    return spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+}
+
+bool use_wgrad_deep()
+{
+    static int deep = -1;
+    if (deep < 0) {
+        const char *e = getenv("MMK_WGRAD_DEEP");
+        deep = (e && e[0] == '0') ? 0 : 1;
+    }
+    return deep == 1;
+}
+
+bool wgrad_is_deep(int cout, int cin, int c1) { return use_wgrad_deep() && cin % 64 == 0 && cout % 64 == 0 && c1 % 64 == 0; }
 
 int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
 {
@@ -1412,10 +1448,8 @@ int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set[dev & 63] = true;
     }
-    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+    const int spatial = wgrad_deep_slices(a.COUT, a.CIN, a.B, a.H, a.W);
     const int chunks = a.CIN / 64, groups = a.COUT / 64;
-    int spatial = 256 / (chunks * groups);            // one 8-wave block per CU
-    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
     hipLaunchKernelGGL(conv3x3_wgrad_deep_kernel, dim3(spatial, chunks, groups), dim3(WGD_THREADS), smem, st, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
@@ -1423,12 +1457,11 @@ int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
 
 int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
 {
-    static int deep = -1;
-    if (deep < 0) {
-        const char *e = getenv("MMK_WGRAD_DEEP");
-        deep = (e && e[0] == '0') ? 0 : 1;
+    if (wgrad_is_deep(a.COUT, a.CIN, a.C1)) return launch_wgrad_deep(a, st);
+    if (a.partials) {
+        mmk::set_error("mmk_conv3x3_wgrad_partial: no partial-sum kernel for CIN=%d COUT=%d (mmk_conv3x3_wgrad_slices is 0)", a.CIN, a.COUT);
+        return MMK_ERR_ARG;
     }
-    if (deep && a.CIN % 64 == 0 && a.COUT % 64 == 0 && a.C1 % 64 == 0) return launch_wgrad_deep(a, st);
     const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
 #define MMK_WG_CASE(K, M) if (CK == K && CM == M) return (M == 16 && a.COUT == 8) ? launch_wgrad<K, M, (M == 16)>(a, st) : launch_wgrad<K, M, false>(a, st)
     MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);
@@ -1452,21 +1485,38 @@ __global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int
 }
 
 struct UnpackBatch {
-    const float *dWt[PACK_BATCH_MAX];
+    const float *src[PACK_BATCH_MAX];     // dWt (9,cout,cin), or per-block partial sums (slices,9,cout,cin)
     float *dW[PACK_BATCH_MAX];
-    int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX];
+    int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX], slices[PACK_BATCH_MAX];
 };
 
-__global__ void unpack_wgrad_batch_kernel(const UnpackBatch ub)
+// One block = 32 consecutive (tap, co, ci) elements x 8 groups of slices: coalesced 128-byte reads of
+// every slice, LDS sum over the groups, transposed write to [co][ci][tap].
+__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch ub)
 {
+    __shared__ float red[8][33];
     const int l = blockIdx.y;
     const int COUT = ub.cout[l], CIN = ub.cin[l];
     const int total = COUT * CIN * 9;
-    const float *__restrict__ src = ub.dWt[l];
+    const int S = ub.slices[l] > 0 ? ub.slices[l] : 1;
+    const float *__restrict__ src = ub.src[l];
     float *__restrict__ dst = ub.dW[l];
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-        dst[e] = src[((size_t)tap * COUT + co) * CIN + ci];
+    const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    for (int e0 = blockIdx.x * 32; e0 < total; e0 += gridDim.x * 32) {
+        const int e = e0 + el;
+        float v = 0.f;
+        if (e < total)
+            for (int sl = sg; sl < S; sl += 8) v += src[(size_t)sl * total + e];
+        red[sg][el] = v;
+        __syncthreads();
+        if (sg == 0 && e < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k][el];
+            const int ci = e % CIN, co = (e / CIN) % COUT, tap = e / (CIN * COUT);
+            dst[((size_t)co * CIN + ci) * 9 + tap] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1989,6 +2039,7 @@ extern "C" int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int
     WgradArgs a;
     a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
     a.dWt = dWt; a.db = db; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+    a.partials = nullptr; a.acc_partials = 0;
     return dispatch_wgrad(a, (hipStream_t)stream);
 }
 
@@ -2003,25 +2054,48 @@ extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t 
     return MMK_OK;
 }
 
-extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *dWt, const int32_t *cout, const int32_t *cin,
-                                              float *const *dW, void *stream)
+extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int32_t *slices, const int32_t *cout,
+                                              const int32_t *cin, float *const *dW, void *stream)
 {
-    MMK_REQUIRE(n >= 1 && dWt && cout && cin && dW, "mmk_conv3x3_wgrad_unpack_batch: bad argument");
+    MMK_REQUIRE(n >= 1 && src && cout && cin && dW, "mmk_conv3x3_wgrad_unpack_batch: bad argument");
     for (int base = 0; base < n; base += PACK_BATCH_MAX) {
         UnpackBatch ub;
         const int m = std::min(PACK_BATCH_MAX, n - base);
         int most = 0;
         for (int i = 0; i < PACK_BATCH_MAX; ++i) {
             const int k = base + (i < m ? i : 0);
-            MMK_REQUIRE(dWt[k] && dW[k] && cout[k] >= 1 && cin[k] >= 1, "mmk_conv3x3_wgrad_unpack_batch: bad layer %d", k);
-            ub.dWt[i] = dWt[k]; ub.dW[i] = dW[k]; ub.cout[i] = cout[k]; ub.cin[i] = cin[k];
+            MMK_REQUIRE(src[k] && dW[k] && cout[k] >= 1 && cin[k] >= 1, "mmk_conv3x3_wgrad_unpack_batch: bad layer %d", k);
+            ub.src[i] = src[k]; ub.dW[i] = dW[k]; ub.cout[i] = cout[k]; ub.cin[i] = cin[k];
+            ub.slices[i] = slices ? slices[k] : 0;
             most = std::max(most, cout[k] * cin[k] * 9);
         }
-        const unsigned bx = (unsigned)std::min((most + 255) / 256, 256);
+        const unsigned bx = (unsigned)std::min((most + 31) / 32, 2048);
         hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
         MMK_LAUNCH_CHECK();
     }
     return MMK_OK;
+}
+
+extern "C" int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t B, int32_t H, int32_t W)
+{
+    if (cout < 1 || cin < 1 || B < 1 || H < 1 || W < 1) return 0;
+    return wgrad_is_deep(cout, cin, c1) ? wgrad_deep_slices(cout, cin, B, H, W) : 0;
+}
+
+extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
+                                         int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, float *db,
+                                         void *stream)
+{
+    MMK_REQUIRE(x1 && g && partials, "mmk_conv3x3_wgrad_partial: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 1 && W >= 1, "mmk_conv3x3_wgrad_partial: bad shape");
+    const int cin = C1 + C2;
+    MMK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || x2), "mmk_conv3x3_wgrad_partial: bad input split %d+%d", C1, C2);
+    MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3_wgrad_partial: unsupported channel counts %d -> %d", cin, cout);
+    WgradArgs a;
+    a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
+    a.dWt = nullptr; a.db = db; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+    a.partials = partials; a.acc_partials = accumulate;
+    return dispatch_wgrad(a, (hipStream_t)stream);
 }
 
 static unsigned nblk(size_t n, int t) { return (unsigned)((n + t - 1) / t); }
