@@ -210,8 +210,8 @@ int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, co
                       int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream);
 int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
                              void *stream);
-/* Partial-sum form of the weight gradient for the shapes where mmk_conv3x3_wgrad_slices() > 0 (both channel
- * counts multiples of 64): every workgroup stores its own (9,cout,cin) slice of `partials`
+/* Partial-sum form of the weight gradient (mmk_conv3x3_wgrad_slices() = number of slices for a shape on the
+ * current device, 0 = unsupported shape): every workgroup stores its own (9,cout,cin) slice of `partials`
  * (slices,9,cout,cin) with plain stores (accumulate != 0: adds to it -- second application of shared
  * weights) and mmk_conv3x3_wgrad_unpack_batch sums the slices: no float atomics, bit-reproducible. */
 int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t B, int32_t H, int32_t W);

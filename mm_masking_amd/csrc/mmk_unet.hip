@@ -1193,34 +1193,54 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
                     tap = 2 * nt + (i16 >> 3);
                     ci = i16 & 7;
                 }
-                if (tap < 9) atomicAdd(&a.dWt[((size_t)tap * a.COUT + co) * a.CIN + ci], acc[m][n][rr]);
+                if (tap < 9) {
+                    if (a.partials) {       // this block's own slice, plain stores (see the 8-wave kernel)
+                        float *d = a.partials + (((size_t)blockIdx.x * 9 + tap) * a.COUT + co) * a.CIN + ci;
+                        *d = a.acc_partials ? *d + acc[m][n][rr] : acc[m][n][rr];
+                    } else {
+                        atomicAdd(&a.dWt[((size_t)tap * a.COUT + co) * a.CIN + ci], acc[m][n][rr]);
+                    }
+                }
             }
             if (a.db && wv == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
         }
     }
 }
 
+// blocks along the pixel tiles (= partial slices of dW): what the 256 CUs hold at once (every extra
+// block costs one more pass over its dW slice); -1 on a HIP error
 template <int CK, int CM, bool G8>
-int launch_wgrad(const WgradArgs &a, hipStream_t st)
+int wgrad_spatial(int cout, int cin, int B, int H, int W)
 {
     const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(G8 ? 8 : CM)) * sizeof(bf16);
     static int per_cu[64] = {};      // resident blocks per CU (registers / LDS), per device
     int dev = 0;
-    MMK_CHECK_HIP(hipGetDevice(&dev));
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (per_cu[dev & 63] == 0) {
-        if (smem > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM, G8>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<CK, CM, G8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return -1;
         int nblk = 0;
-        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_wgrad_kernel<CK, CM, G8>, CONV_THREADS, smem));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_wgrad_kernel<CK, CM, G8>, CONV_THREADS, smem) != hipSuccess)
+            return -1;
         per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
     }
-    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
-    const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
-    // persistent grid sized to what the 256 CUs hold at once: every extra block costs one more
-    // fp32 atomic pass over its dW slice
+    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int chunks = cin / CK, groups = (cout + CM - 1) / CM;
     int spatial = (256 * per_cu[dev & 63]) / (chunks * groups);
-    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    return spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+}
+
+template <int CK, int CM, bool G8>
+int launch_wgrad(const WgradArgs &a, hipStream_t st)
+{
+    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(G8 ? 8 : CM)) * sizeof(bf16);
+    const int spatial = wgrad_spatial<CK, CM, G8>(a.COUT, a.CIN, a.B, a.H, a.W);
+    if (spatial < 1) {
+        mmk::set_error("mmk_conv3x3_wgrad: occupancy query failed");
+        return MMK_ERR_HIP;
+    }
+    const int chunks = a.CIN / CK, groups = (a.COUT + CM - 1) / CM;
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<CK, CM, G8>), dim3(spatial, chunks, groups), dim3(CONV_THREADS), smem, st, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
@@ -1458,10 +1478,6 @@ int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
 int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
 {
     if (wgrad_is_deep(a.COUT, a.CIN, a.C1)) return launch_wgrad_deep(a, st);
-    if (a.partials) {
-        mmk::set_error("mmk_conv3x3_wgrad_partial: no partial-sum kernel for CIN=%d COUT=%d (mmk_conv3x3_wgrad_slices is 0)", a.CIN, a.COUT);
-        return MMK_ERR_ARG;
-    }
     const int CK = cin_chunk(a.CIN), CM = cout_group(a.COUT);
 #define MMK_WG_CASE(K, M) if (CK == K && CM == M) return (M == 16 && a.COUT == 8) ? launch_wgrad<K, M, (M == 16)>(a, st) : launch_wgrad<K, M, false>(a, st)
     MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);
@@ -1471,6 +1487,20 @@ int dispatch_wgrad(const WgradArgs &a, hipStream_t st)
 #undef MMK_WG_CASE
     mmk::set_error("mmk_conv3x3_wgrad: unsupported channel counts CIN=%d COUT=%d", a.CIN, a.COUT);
     return MMK_ERR_ARG;
+}
+
+// number of partial slices (= blocks along the tiles) the kernel dispatch_wgrad picks will run with
+int wgrad_slices(int cout, int cin, int c1, int B, int H, int W)
+{
+    if (wgrad_is_deep(cout, cin, c1)) return wgrad_deep_slices(cout, cin, B, H, W);
+    const int CK = cin_chunk(cin), CM = cout_group(cout);
+#define MMK_WG_CASE(K, M) if (CK == K && CM == M) return (M == 16 && cout == 8) ? wgrad_spatial<K, M, (M == 16)>(cout, cin, B, H, W) : wgrad_spatial<K, M, false>(cout, cin, B, H, W)
+    MMK_WG_CASE(8, 16); MMK_WG_CASE(8, 32); MMK_WG_CASE(8, 64);
+    MMK_WG_CASE(16, 16); MMK_WG_CASE(16, 32); MMK_WG_CASE(16, 64);
+    MMK_WG_CASE(32, 16); MMK_WG_CASE(32, 32); MMK_WG_CASE(32, 64);
+    MMK_WG_CASE(64, 16); MMK_WG_CASE(64, 32); MMK_WG_CASE(64, 64);
+#undef MMK_WG_CASE
+    return 0;
 }
 
 // dW[co][ci][tap] (+)= dWt[tap][co][ci]
@@ -2078,8 +2108,9 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
 
 extern "C" int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t B, int32_t H, int32_t W)
 {
-    if (cout < 1 || cin < 1 || B < 1 || H < 1 || W < 1) return 0;
-    return wgrad_is_deep(cout, cin, c1) ? wgrad_deep_slices(cout, cin, B, H, W) : 0;
+    if (B < 1 || H < 1 || W < 1 || !chan_ok(cin) || !chan_ok(cout)) return 0;
+    const int ns = wgrad_slices(cout, cin, c1, B, H, W);
+    return ns < 0 ? 0 : ns;
 }
 
 extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,

@@ -137,7 +137,7 @@ def test_conv3x3_wgrad(cin, cout, H, W):
     assert (acc - (2 * w.grad + 1)).abs().max().item() < 4e-3 * scale + 2e-3
     # partial-sum form (no float atomics) where the library offers it; two applications accumulate
     ns = uh.wgrad_slices(cout, cin, cin, B, H, W)
-    assert (ns > 0) == (cin % 64 == 0 and cout % 64 == 0)
+    assert ns > 0
     if ns > 0:
         part = torch.full((ns, 9, cout, cin), float("nan"), device=DEV)      # must be fully overwritten
         db2 = torch.zeros(cout, device=DEV)
