@@ -775,11 +775,20 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         }
     };
 
+    // the accumulators start from the bias (re-read per tile: keeping it in registers across the MFMA
+    // loop would not fit)
     f32x4 acc[MT][NT];
+    auto reset_acc = [&]() {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const int c0 = group * BM + (wm * MT + m) * 16 + (lane >> 4) * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && c0 < a.COUT) bv = *reinterpret_cast<const f32x4 *>(a.bias + c0);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NT; ++n) acc[m][n] = bv;
+        }
+    };
+    reset_acc();
 
     const DropoutParams dp = dropout_params(a.drop_p);
     // fragment addresses that do not depend on the stage
@@ -830,9 +839,114 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
             const int b = tile / tpi, tr = tile - b * tpi;
             const int tyi = tr / tiles_x;
             const int tx0 = (tr - tyi * tiles_x) * C::TWD, yy = tyi * C::TH + wn;
+            // Wide path (the wave's four 16-channel tiles all exist, output parts split on a multiple of
+            // 16): the MFMA layout gives a lane 4 channels of each of 4 tiles = four 8-byte pieces 32
+            // bytes apart; a 4x4 transpose across the lane groups (2 x v_permlane32_swap +
+            // 2 x v_permlane16_swap per dword) gives it 16 consecutive channels = 32 contiguous bytes,
+            // so a wave touches full 128-byte lines.  (8-byte pieces of 256-byte pixel rows cost 4x the
+            // algorithmic HBM write traffic: profiles/r01e_conv_traffic.json.)
+            // (the lane index behind an opaque asm: the per-lane output pointers are derived here, once per
+            // tile, instead of living in ~16 registers across the MFMA loop)
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+            bool wide = false;
+            if constexpr (MT == 4) wide = (group * BM + (wm + 1) * 64 <= a.COUT) && (a.o1.C % 16 == 0);
+            if (wide) {
+                if constexpr (MT == 4) {
+                    const int g4 = lv >> 4;
+                    const int ct = group * BM + wm * 64 + g4 * 16;       // first of this lane's 16 channels (transposed)
+                    const bool fpt = ct < a.o1.C;
+                    bf16 *t_y = fpt ? a.o1.y : a.o2.y;
+                    const bf16 *t_src = fpt ? a.o1.relu_src : a.o2.relu_src;
+                    const int t_C = fpt ? a.o1.C : a.o2.C;
+                    const bool t_acc = (fpt ? a.o1.accumulate : a.o2.accumulate) != 0;
+                    const int t_cl = fpt ? ct : ct - a.o1.C;
+                    bool m_has_src[4];
+                    float m_scale[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
+                        const bool firstp = c0 < a.o1.C;
+                        m_has_src[m] = (firstp ? a.o1.relu_src : a.o2.relu_src) != nullptr;
+                        m_scale[m] = firstp ? a.o1.scale : a.o2.scale;
+                    }
+                    auto transpose4 = [](unsigned (&x)[4]) {
+                        auto r02 = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false);
+                        auto r13 = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false);
+                        auto r01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);
+                        auto r23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);
+                        x[0] = r01[0]; x[1] = r01[1]; x[2] = r23[0]; x[3] = r23[1];
+                    };
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int xx = tx0 + n * 16 + (lv & 15);
+                        const bool okp = yy < a.H && xx < a.W;
+                        const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
+                        bf16 *tdst = t_y + p * t_C + t_cl;
+                        unsigned slo[4] = {0, 0, 0, 0}, shi[4] = {0, 0, 0, 0}, alo[4] = {0, 0, 0, 0}, ahi[4] = {0, 0, 0, 0};
+                        if (t_src != nullptr && okp) {
+                            const u32x4 v0 = *reinterpret_cast<const u32x4 *>(t_src + p * t_C + t_cl);
+                            const u32x4 v1 = *reinterpret_cast<const u32x4 *>(t_src + p * t_C + t_cl + 8);
+                            slo[0] = v0[0]; shi[0] = v0[1]; slo[1] = v0[2]; shi[1] = v0[3];
+                            slo[2] = v1[0]; shi[2] = v1[1]; slo[3] = v1[2]; shi[3] = v1[3];
+                        }
+                        if (t_acc && okp) {
+                            const u32x4 v0 = *reinterpret_cast<const u32x4 *>(tdst);
+                            const u32x4 v1 = *reinterpret_cast<const u32x4 *>(tdst + 8);
+                            alo[0] = v0[0]; ahi[0] = v0[1]; alo[1] = v0[2]; ahi[1] = v0[3];
+                            alo[2] = v1[0]; ahi[2] = v1[1]; alo[3] = v1[2]; ahi[3] = v1[3];
+                        }
+                        const bool any_src = a.o1.relu_src != nullptr || a.o2.relu_src != nullptr;
+                        const bool any_acc = a.o1.accumulate != 0 || a.o2.accumulate != 0;
+                        if (any_src) { transpose4(slo); transpose4(shi); }     // back to the MFMA layout
+                        if (any_acc) { transpose4(alo); transpose4(ahi); }
+                        unsigned lo[4], hi[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = acc[m][n][r];
+                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            if (a.drop_p > 0.f) {
+                                float sc[4];
+                                const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
+                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                            }
+                            if (m_has_src[m]) {
+                                const bf16x4 sv = __builtin_bit_cast(bf16x4, (unsigned long long)slo[m] | ((unsigned long long)shi[m] << 32));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * m_scale[m] : 0.f;
+                            }
+                            if (any_acc) {
+                                const bf16x4 ov = __builtin_bit_cast(bf16x4, (unsigned long long)alo[m] | ((unsigned long long)ahi[m] << 32));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];      // zeros where the part does not accumulate
+                            }
+                            bf16x4 outv;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
+                            const unsigned long long pk = __builtin_bit_cast(unsigned long long, outv);
+                            lo[m] = (unsigned)pk;
+                            hi[m] = (unsigned)(pk >> 32);
+                        }
+                        transpose4(lo);
+                        transpose4(hi);
+                        if (okp) {
+                            const u32x4 w0 = {lo[0], hi[0], lo[1], hi[1]};
+                            const u32x4 w1 = {lo[2], hi[2], lo[3], hi[3]};
+                            *reinterpret_cast<u32x4 *>(tdst) = w0;
+                            *reinterpret_cast<u32x4 *>(tdst + 8) = w1;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int c0 = group * BM + (wm * MT + m) * 16 + (lane >> 4) * 4;
+                const int c0 = group * BM + (wm * MT + m) * 16 + (lv >> 4) * 4;
                 if (c0 < a.COUT) {
                     const bool firstp = c0 < a.o1.C;
                     bf16 *o_y = firstp ? a.o1.y : a.o2.y;
@@ -841,20 +955,15 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                     const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
                     const float o_scale = firstp ? a.o1.scale : a.o2.scale;
                     const int cl = firstp ? c0 : c0 - a.o1.C;
-                    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bs[r] = a.bias[c0 + r];
-                    }
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const int xx = tx0 + n * 16 + (lane & 15);
+                        const int xx = tx0 + n * 16 + (lv & 15);
                         if (yy < a.H && xx < a.W) {
                             const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[m][n][r] + bs[r];
+                                v[r] = acc[m][n][r];
                                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
@@ -881,9 +990,9 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                         }
                     }
                 }
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            }
+            reset_acc();
         }
         if (!has_next) break;
         __syncthreads();

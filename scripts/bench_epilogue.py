@@ -1,9 +1,9 @@
 """Epilogue cost probe for the full-resolution conv layers (development tool)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, "."); sys.path.insert(0, "scripts")
 from mm_masking_amd import unet_hip as uh
-from tools.bench_layers import rnd, timeit, DEV
+from bench_layers import rnd, timeit, DEV
 
 B, H = 32, 640
 for cin, co in [(8, 8), (8, 16), (16, 16), (16, 8)]:
