@@ -839,28 +839,37 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
             const int b = tile / tpi, tr = tile - b * tpi;
             const int tyi = tr / tiles_x;
             const int tx0 = (tr - tyi * tiles_x) * C::TWD, yy = tyi * C::TH + wn;
-            // Wide path (the wave's four 16-channel tiles all exist, output parts split on a multiple of
-            // 16): the MFMA layout gives a lane 4 channels of each of 4 tiles = four 8-byte pieces 32
-            // bytes apart; a 4x4 transpose across the lane groups (2 x v_permlane32_swap +
-            // 2 x v_permlane16_swap per dword) gives it 16 consecutive channels = 32 contiguous bytes,
-            // so a wave touches full 128-byte lines.  (8-byte pieces of 256-byte pixel rows cost 4x the
-            // algorithmic HBM write traffic: profiles/r01e_conv_traffic.json.)
+            // Wide path (the wave's four 16-channel tiles all exist): the MFMA layout gives lane group
+            // g = 2a+b (16 lanes each) 4 channels of each tile m = 2c+d, i.e. four 8-byte pieces 32 bytes
+            // apart.  One v_permlane16_swap per dword and tile pair (m = 2c, 2c+1) trades lane bit b for
+            // tile bit d; the lane then owns the two adjacent pieces 8c + 4b + 2a + {0,1} = 16 contiguous
+            // bytes at channel 32c + 16b + 8a, and one store instruction (fixed c) covers 64 contiguous
+            // bytes per pixel.  (8-byte pieces of 256-byte pixel rows cost 4x the algorithmic HBM write
+            // traffic: profiles/r01e_conv_traffic.json.)  Operands of the epilogue take the same route back.
             // (the lane index behind an opaque asm: the per-lane output pointers are derived here, once per
             // tile, instead of living in ~16 registers across the MFMA loop)
             int lv = lane;
             asm volatile("" : "+v"(lv));
             bool wide = false;
-            if constexpr (MT == 4) wide = (group * BM + (wm + 1) * 64 <= a.COUT) && (a.o1.C % 16 == 0);
+            if constexpr (MT == 4) wide = (group * BM + (wm + 1) * 64 <= a.COUT);
             if (wide) {
                 if constexpr (MT == 4) {
                     const int g4 = lv >> 4;
-                    const int ct = group * BM + wm * 64 + g4 * 16;       // first of this lane's 16 channels (transposed)
-                    const bool fpt = ct < a.o1.C;
-                    bf16 *t_y = fpt ? a.o1.y : a.o2.y;
-                    const bf16 *t_src = fpt ? a.o1.relu_src : a.o2.relu_src;
-                    const int t_C = fpt ? a.o1.C : a.o2.C;
-                    const bool t_acc = (fpt ? a.o1.accumulate : a.o2.accumulate) != 0;
-                    const int t_cl = fpt ? ct : ct - a.o1.C;
+                    const int lane_ch = 16 * (g4 & 1) + 8 * (g4 >> 1);          // + 32 c
+                    bf16 *t_y[2];
+                    const bf16 *t_src[2];
+                    int t_C[2], t_cl[2];
+                    bool t_acc[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int ct = group * BM + wm * 64 + 32 * c + lane_ch;
+                        const bool fpt = ct < a.o1.C;
+                        t_y[c] = fpt ? a.o1.y : a.o2.y;
+                        t_src[c] = fpt ? a.o1.relu_src : a.o2.relu_src;
+                        t_C[c] = fpt ? a.o1.C : a.o2.C;
+                        t_acc[c] = (fpt ? a.o1.accumulate : a.o2.accumulate) != 0;
+                        t_cl[c] = fpt ? ct : ct - a.o1.C;
+                    }
                     bool m_has_src[4];
                     float m_scale[4];
 #pragma unroll
@@ -870,36 +879,33 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                         m_has_src[m] = (firstp ? a.o1.relu_src : a.o2.relu_src) != nullptr;
                         m_scale[m] = firstp ? a.o1.scale : a.o2.scale;
                     }
-                    auto transpose4 = [](unsigned (&x)[4]) {
-                        auto r02 = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false);
-                        auto r13 = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false);
-                        auto r01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);
-                        auto r23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);
+                    // x[m] <-> the piece layout (an involution)
+                    auto swap16 = [](unsigned (&x)[4]) {
+                        auto r01 = __builtin_amdgcn_permlane16_swap(x[0], x[1], false, false);
+                        auto r23 = __builtin_amdgcn_permlane16_swap(x[2], x[3], false, false);
                         x[0] = r01[0]; x[1] = r01[1]; x[2] = r23[0]; x[3] = r23[1];
                     };
+                    const bool any_src = a.o1.relu_src != nullptr || a.o2.relu_src != nullptr;
+                    const bool any_acc = a.o1.accumulate != 0 || a.o2.accumulate != 0;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int xx = tx0 + n * 16 + (lv & 15);
                         const bool okp = yy < a.H && xx < a.W;
                         const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                        bf16 *tdst = t_y + p * t_C + t_cl;
                         unsigned slo[4] = {0, 0, 0, 0}, shi[4] = {0, 0, 0, 0}, alo[4] = {0, 0, 0, 0}, ahi[4] = {0, 0, 0, 0};
-                        if (t_src != nullptr && okp) {
-                            const u32x4 v0 = *reinterpret_cast<const u32x4 *>(t_src + p * t_C + t_cl);
-                            const u32x4 v1 = *reinterpret_cast<const u32x4 *>(t_src + p * t_C + t_cl + 8);
-                            slo[0] = v0[0]; shi[0] = v0[1]; slo[1] = v0[2]; shi[1] = v0[3];
-                            slo[2] = v1[0]; shi[2] = v1[1]; slo[3] = v1[2]; shi[3] = v1[3];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            if (t_src[c] != nullptr && okp) {
+                                const u32x4 v = *reinterpret_cast<const u32x4 *>(t_src[c] + p * t_C[c] + t_cl[c]);
+                                slo[2 * c] = v[0]; shi[2 * c] = v[1]; slo[2 * c + 1] = v[2]; shi[2 * c + 1] = v[3];
+                            }
+                            if (t_acc[c] && okp) {
+                                const u32x4 v = *reinterpret_cast<const u32x4 *>(t_y[c] + p * t_C[c] + t_cl[c]);
+                                alo[2 * c] = v[0]; ahi[2 * c] = v[1]; alo[2 * c + 1] = v[2]; ahi[2 * c + 1] = v[3];
+                            }
                         }
-                        if (t_acc && okp) {
-                            const u32x4 v0 = *reinterpret_cast<const u32x4 *>(tdst);
-                            const u32x4 v1 = *reinterpret_cast<const u32x4 *>(tdst + 8);
-                            alo[0] = v0[0]; ahi[0] = v0[1]; alo[1] = v0[2]; ahi[1] = v0[3];
-                            alo[2] = v1[0]; ahi[2] = v1[1]; alo[3] = v1[2]; ahi[3] = v1[3];
-                        }
-                        const bool any_src = a.o1.relu_src != nullptr || a.o2.relu_src != nullptr;
-                        const bool any_acc = a.o1.accumulate != 0 || a.o2.accumulate != 0;
-                        if (any_src) { transpose4(slo); transpose4(shi); }     // back to the MFMA layout
-                        if (any_acc) { transpose4(alo); transpose4(ahi); }
+                        if (any_src) { swap16(slo); swap16(shi); }     // back to the MFMA layout
+                        if (any_acc) { swap16(alo); swap16(ahi); }
                         unsigned lo[4], hi[4];
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
@@ -933,13 +939,14 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                             lo[m] = (unsigned)pk;
                             hi[m] = (unsigned)(pk >> 32);
                         }
-                        transpose4(lo);
-                        transpose4(hi);
+                        swap16(lo);
+                        swap16(hi);
                         if (okp) {
-                            const u32x4 w0 = {lo[0], hi[0], lo[1], hi[1]};
-                            const u32x4 w1 = {lo[2], hi[2], lo[3], hi[3]};
-                            *reinterpret_cast<u32x4 *>(tdst) = w0;
-                            *reinterpret_cast<u32x4 *>(tdst + 8) = w1;
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const u32x4 w = {lo[2 * c], hi[2 * c], lo[2 * c + 1], hi[2 * c + 1]};
+                                *reinterpret_cast<u32x4 *>(t_y[c] + p * t_C[c] + t_cl[c]) = w;
+                            }
                         }
                     }
                 }
