@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SO_PATH = os.path.join(_HERE, "libmmk_hip.so")
+SO_PATH = os.environ.get("MMK_LIB", os.path.join(_HERE, "libmmk_hip.so"))   # MMK_LIB: A/B another build (development)
 SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip"]
 
 _lib = None

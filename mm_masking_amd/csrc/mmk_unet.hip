@@ -1234,14 +1234,28 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         }
     };
 
-    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    // XCD-contiguous tile walk (workgroups are dealt to the 8 XCDs round-robin by their linear id; the
+    // launcher makes gridDim.x a multiple of 8, so that is blockIdx.x & 7): each XCD works through its
+    // own eighth of the tiles and the halo rows shared by neighbouring tiles are fetched into one L2
+    // only.  A block without tiles still writes its (zero) partial slice.
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
         __syncthreads();
         store_tile();
         __syncthreads();
         {
-            const int nt = t + (int)gridDim.x;
-            load_tile(nt < total_tiles ? nt : t);
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);
         }
         // fragments of tile row r+1 are fetched from LDS while the matrix cores consume row r; the
         // rows are unrolled so that every read carries its row offset as an immediate
@@ -1344,7 +1358,8 @@ int wgrad_spatial(int cout, int cin, int B, int H, int W)
     const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int chunks = cin / CK, groups = (cout + CM - 1) / CM;
     int spatial = (256 * per_cu[dev & 63]) / (chunks * groups);
-    return spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    return spatial >= 8 ? (spatial & ~7) : spatial;      // multiple of 8: XCD-contiguous tile walk
 }
 
 template <int CK, int CM, bool G8>
@@ -1463,14 +1478,25 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
         }
     };
 
-    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    // XCD-contiguous tile walk (see conv3x3_wgrad_kernel)
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
         __syncthreads();
         store_tile();
         __syncthreads();
         {
-            const int nt = t + (int)gridDim.x;
-            load_tile(nt < total_tiles ? nt : t);       // (clamped: the loads stay unconditional)
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);       // (clamped: the loads stay unconditional)
         }
         // fragment registers: x row rho in fb, g rows rho-2 .. rho in a ring of 3.  The reads of row
         // rho+1 are issued right behind row rho's MFMAs (which have read their operands by then) and
@@ -1559,7 +1585,8 @@ int wgrad_deep_slices(int cout, int cin, int B, int H, int W)
     const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int chunks = cin / 64, groups = cout / 64;
     int spatial = 256 / (chunks * groups);            // one 8-wave block per CU
-    return spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    spatial = spatial < 1 ? 1 : (spatial > tiles ? tiles : spatial);
+    return spatial >= 8 ? (spatial & ~7) : spatial;   // multiple of 8: XCD-contiguous tile walk
 }
 
 bool use_wgrad_deep()
