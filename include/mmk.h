@@ -211,17 +211,18 @@ int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, co
 int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
                              void *stream);
 /* Partial-sum form of the weight gradient (mmk_conv3x3_wgrad_slices() = number of slices for a shape on the
- * current device, 0 = unsupported shape): every workgroup stores its own (9,cout,cin) slice of `partials`
- * (slices,9,cout,cin) with plain stores (accumulate != 0: adds to it -- second application of shared
- * weights) and mmk_conv3x3_wgrad_unpack_batch sums the slices: no float atomics, bit-reproducible. */
+ * current device, 0 = unsupported shape): every workgroup stores its own slice of `partials`
+ * (slices, 9*cout*cin + cout) -- the (9,cout,cin) weight sums followed by the cout bias sums -- with plain
+ * stores (accumulate != 0: adds to it -- second application of shared weights) and
+ * mmk_conv3x3_wgrad_unpack_batch sums the slices: no float atomics, bit-reproducible. */
 int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t B, int32_t H, int32_t W);
 int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
-                              int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, float *db,
-                              void *stream);
+                              int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, void *stream);
 /* n layers in one launch (no accumulation): dW[i] (cout,cin,3,3) = src[i] (9,cout,cin) when slices is NULL or
- * slices[i] == 0, else the sum over the slices[i] partial slices of src[i] (slices,9,cout,cin) */
+ * slices[i] == 0; else the sum over the slices[i] partial slices of src[i], and db[i] (cout, optional) their
+ * bias sums */
 int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int32_t *slices, const int32_t *cout,
-                                   const int32_t *cin, float *const *dW, void *stream);
+                                   const int32_t *cin, float *const *dW, float *const *db, void *stream);
 
 /* First conv of the network (encoder.0.0): fp32 NCHW input (B,cin,H,W), cin = 1..4
  * (fft | cfar | range channels, icp_weight_policy.py:84), W[8][cin][3][3], + bias + ReLU ->

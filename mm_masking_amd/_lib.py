@@ -95,9 +95,9 @@ def _declare(lib):
         "mmk_conv3x3": (ctypes.c_int, [ctypes.POINTER(ConvDesc), c_vp]),
         "mmk_conv3x3_wgrad": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_unpack": (ctypes.c_int, [c_vp, i32, i32, i32, c_vp, c_vp]),
-        "mmk_conv3x3_wgrad_unpack_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_conv3x3_wgrad_unpack_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_slices": (i32, [i32, i32, i32, i32, i32, i32]),
-        "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp, c_vp]),
+        "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
         "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
         "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),

@@ -1304,7 +1304,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 #undef WG_ISSUE
     }
 
-    // ---- one atomic pass per block
+    // ---- flush: the block's partial slice (9*COUT*CIN weight sums + COUT bias sums), or atomics
+    const size_t pstride = (size_t)9 * a.COUT * a.CIN + a.COUT;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -1325,14 +1326,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
                 }
                 if (tap < 9) {
                     if (a.partials) {       // this block's own slice, plain stores (see the 8-wave kernel)
-                        float *d = a.partials + (((size_t)blockIdx.x * 9 + tap) * a.COUT + co) * a.CIN + ci;
+                        float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * a.COUT + co) * a.CIN + ci;
                         *d = a.acc_partials ? *d + acc[m][n][rr] : acc[m][n][rr];
                     } else {
                         atomicAdd(&a.dWt[((size_t)tap * a.COUT + co) * a.CIN + ci], acc[m][n][rr]);
                     }
                 }
             }
-            if (a.db && wv == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
+            if (wv == 0 && chunk == 0 && i16 == 0) {
+                if (a.partials) {           // bias partial: last COUT floats of the slice
+                    float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
+                    *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
+                } else if (a.db) {
+                    atomicAdd(&a.db[co], accb[m][rr]);
+                }
+            }
         }
     }
 }
@@ -1549,7 +1557,8 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
 #undef WGD_ISSUE
     }
 
-    // ---- one atomic pass per block
+    // ---- flush: the block's partial slice (9*COUT*CIN weight sums + COUT bias sums), or atomics
+    const size_t pstride = (size_t)9 * a.COUT * a.CIN + a.COUT;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -1559,7 +1568,7 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
             if (a.partials) {
                 // plain stores into this block's own slice (summed by the unpack kernel): float atomics
                 // run at ~1.3 TB/s and 256 blocks x 147 KB of them cost 30-35 us per launch
-                float *ps = a.partials + (size_t)blockIdx.x * 9 * a.COUT * a.CIN + (size_t)co * a.CIN + ci;
+                float *ps = a.partials + (size_t)blockIdx.x * pstride + (size_t)co * a.CIN + ci;
 #pragma unroll
                 for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -1574,7 +1583,14 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
                     for (int tx = 0; tx < 3; ++tx)
                         atomicAdd(&a.dWt[((size_t)(ty * 3 + tx) * a.COUT + co) * a.CIN + ci], acc[ty][tx][m][rr]);
             }
-            if (a.db && wc == 0 && chunk == 0 && i16 == 0) atomicAdd(&a.db[co], accb[m][rr]);
+            if (wc == 0 && chunk == 0 && i16 == 0) {
+                if (a.partials) {           // bias partial: last COUT floats of the slice
+                    float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
+                    *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
+                } else if (a.db) {
+                    atomicAdd(&a.db[co], accb[m][rr]);
+                }
+            }
         }
     }
 }
@@ -1658,22 +1674,26 @@ __global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int
 }
 
 struct UnpackBatch {
-    const float *src[PACK_BATCH_MAX];     // dWt (9,cout,cin), or per-block partial sums (slices,9,cout,cin)
+    const float *src[PACK_BATCH_MAX];     // dWt (9,cout,cin), or per-block partial slices (slices, 9*cout*cin + cout)
     float *dW[PACK_BATCH_MAX];
+    float *db[PACK_BATCH_MAX];            // bias gradient out (partial-slice form only), may be null
     int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX], slices[PACK_BATCH_MAX];
 };
 
-// One block = 32 consecutive (tap, co, ci) elements x 8 groups of slices: coalesced 128-byte reads of
-// every slice, LDS sum over the groups, transposed write to [co][ci][tap].
+// One block = 32 consecutive elements of a slice x 8 groups of slices: coalesced 128-byte reads of every
+// slice, LDS sum over the groups; weight sums go transposed to [co][ci][tap], bias sums to db.
 __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch ub)
 {
     __shared__ float red[8][33];
     const int l = blockIdx.y;
     const int COUT = ub.cout[l], CIN = ub.cin[l];
-    const int total = COUT * CIN * 9;
-    const int S = ub.slices[l] > 0 ? ub.slices[l] : 1;
+    const int nw = COUT * CIN * 9;
+    const bool sliced = ub.slices[l] > 0;
+    const int S = sliced ? ub.slices[l] : 1;
+    const int total = sliced ? nw + COUT : nw;       // elements of one slice
     const float *__restrict__ src = ub.src[l];
     float *__restrict__ dst = ub.dW[l];
+    float *__restrict__ dbo = ub.db[l];
     const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
     for (int e0 = blockIdx.x * 32; e0 < total; e0 += gridDim.x * 32) {
         const int e = e0 + el;
@@ -1686,8 +1706,12 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[k][el];
-            const int ci = e % CIN, co = (e / CIN) % COUT, tap = e / (CIN * COUT);
-            dst[((size_t)co * CIN + ci) * 9 + tap] = t;
+            if (e < nw) {
+                const int ci = e % CIN, co = (e / CIN) % COUT, tap = e / (CIN * COUT);
+                dst[((size_t)co * CIN + ci) * 9 + tap] = t;
+            } else if (dbo) {
+                dbo[e - nw] = t;
+            }
         }
         __syncthreads();
     }
@@ -1855,50 +1879,65 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Wq = W >> 2;
     const int nq = B * H * Wq;
+    const int stride = gridDim.x * blockDim.x;
     for (int c = 0; c < CIN; ++c) {
         float acc[80];
 #pragma unroll
         for (int i = 0; i < 80; ++i) acc[i] = 0.f;
-        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += gridDim.x * blockDim.x) {
+        // operands of the next quad are in flight while the current one is accumulated
+        bf16x8 gv[4], gn[4];
+        float v[3][6], vn[3][6];
+        auto fetch = [&](int e, bf16x8 (&go)[4], float (&vo)[3][6]) {
             const int q = e % Wq, by = e / Wq;
             const int yy = by % H, b = by / H;
             const int x0 = q * 4;
             const float *xc = x + ((size_t)b * CIN + c) * H * W;
-            float gf[4][8];
             const bf16 *gp = g + ((size_t)by * W + x0) * 8;
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(gp + px * 8);
+            for (int px = 0; px < 4; ++px) go[px] = *reinterpret_cast<const bf16x8 *>(gp + px * 8);
 #pragma unroll
-                for (int co = 0; co < 8; ++co) gf[px][co] = (float)gv[co];
-            }
+            for (int dy = 0; dy < 3; ++dy) load_row6(xc, yy + dy - 1, x0, H, W, vo[dy]);
+        };
+        int e = blockIdx.x * blockDim.x + threadIdx.x;
+        if (e < nq) fetch(e, gv, v);
+        for (; e < nq; e += stride) {
+            const int en = e + stride;
+            if (en < nq) fetch(en, gn, vn);
+            float gf[4][8];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float v[6];
-                load_row6(xc, yy + dy - 1, x0, H, W, v);
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int co = 0; co < 8; ++co) gf[px][co] = (float)gv[px][co];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int co = 0; co < 8; ++co)
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) acc[co * 9 + dy * 3 + tx] += gf[px][co] * v[px + tx];
-            }
+                        for (int px = 0; px < 4; ++px) acc[co * 9 + dy * 3 + tx] += gf[px][co] * v[dy][px + tx];
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[72 + co] += (gf[0][co] + gf[1][co]) + (gf[2][co] + gf[3][co]);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) gv[px] = gn[px];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[dy][i] = vn[dy][i];
         }
 #pragma unroll
         for (int i = 0; i < 80; ++i) {
-            float v = acc[i];
+            float t = acc[i];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wv][i] = v;
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) red[wv][i] = t;
         }
         __syncthreads();
         if (threadIdx.x < 80) {
-            const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
             const int i = threadIdx.x;
-            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], v);
-            else if (c == 0 && db) atomicAdd(&db[i - 72], v);
+            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], t);
+            else if (c == 0 && db) atomicAdd(&db[i - 72], t);
         }
         __syncthreads();
     }
@@ -2228,7 +2267,7 @@ extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t 
 }
 
 extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int32_t *slices, const int32_t *cout,
-                                              const int32_t *cin, float *const *dW, void *stream)
+                                              const int32_t *cin, float *const *dW, float *const *db, void *stream)
 {
     MMK_REQUIRE(n >= 1 && src && cout && cin && dW, "mmk_conv3x3_wgrad_unpack_batch: bad argument");
     for (int base = 0; base < n; base += PACK_BATCH_MAX) {
@@ -2240,7 +2279,8 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
             MMK_REQUIRE(src[k] && dW[k] && cout[k] >= 1 && cin[k] >= 1, "mmk_conv3x3_wgrad_unpack_batch: bad layer %d", k);
             ub.src[i] = src[k]; ub.dW[i] = dW[k]; ub.cout[i] = cout[k]; ub.cin[i] = cin[k];
             ub.slices[i] = slices ? slices[k] : 0;
-            most = std::max(most, cout[k] * cin[k] * 9);
+            ub.db[i] = (db && ub.slices[i] > 0) ? db[k] : nullptr;
+            most = std::max(most, cout[k] * cin[k] * 9 + cout[k]);
         }
         const unsigned bx = (unsigned)std::min((most + 31) / 32, 2048);
         hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
@@ -2257,8 +2297,7 @@ extern "C" int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c
 }
 
 extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
-                                         int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, float *db,
-                                         void *stream)
+                                         int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, void *stream)
 {
     MMK_REQUIRE(x1 && g && partials, "mmk_conv3x3_wgrad_partial: NULL pointer");
     MMK_REQUIRE(B >= 1 && H >= 1 && W >= 1, "mmk_conv3x3_wgrad_partial: bad shape");
@@ -2267,7 +2306,7 @@ extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t
     MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3_wgrad_partial: unsupported channel counts %d -> %d", cin, cout);
     WgradArgs a;
     a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
-    a.dWt = nullptr; a.db = db; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+    a.dWt = nullptr; a.db = nullptr; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
     a.partials = partials; a.acc_partials = accumulate;
     return dispatch_wgrad(a, (hipStream_t)stream);
 }
@@ -2299,7 +2338,7 @@ extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, 
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first_wgrad: bad shape");
     const size_t npix = (size_t)B * H * Wd;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
-        const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 2048);
+        const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 512);   // 80 same-address float atomics per block: few blocks
         hipLaunchKernelGGL(conv_first_wgrad_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B,
                            H, Wd, dW, db);
         MMK_LAUNCH_CHECK();
@@ -2368,7 +2407,7 @@ extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, c
                              void *gx, float *dW, float *db, void *stream)
 {
     MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && npix >= 1, "mmk_final_bwd: bad argument");
-    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 2048);
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);   // 9 same-address atomics per block
     hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
                        (size_t)npix, scale, (bf16 *)gx, dW, db);
     MMK_LAUNCH_CHECK();

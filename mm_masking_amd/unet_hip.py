@@ -105,39 +105,52 @@ def dropout_scale(p):
 
 
 def wgrad_slices(cout, cin, c1, B, H, W):
-    """Number of per-workgroup partial slices of the partial-sum weight-gradient kernel (0: atomics path)."""
+    """Number of per-workgroup partial slices of the partial-sum weight-gradient kernel (0: unsupported)."""
     return int(_lib.lib().mmk_conv3x3_wgrad_slices(cout, cin, c1, B, H, W))
 
 
-def conv3x3_wgrad_partial(x1, g, cout, partials, x2=None, db=None, accumulate=False):
-    """Weight gradient as per-workgroup partial sums: partials (slices,9,cout,cin) fp32."""
+def partial_buffer(ns, cout, cin, device):
+    """(slices, 9*cout*cin + cout) fp32: per slice the (9,cout,cin) weight sums, then the cout bias sums."""
+    return torch.empty(ns, 9 * cout * cin + cout, dtype=torch.float32, device=device)
+
+
+def conv3x3_wgrad_partial(x1, g, cout, partials, x2=None, accumulate=False):
+    """Weight + bias gradient as per-workgroup partial sums into `partials` (see partial_buffer)."""
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     _lib.check(_lib.lib().mmk_conv3x3_wgrad_partial(_p(x1), _p(x2), C1, C2, _p(g), cout, B, H, W, _p(partials),
-                                                    1 if accumulate else 0, _p(db), _lib.stream_ptr(x1.device)))
+                                                    1 if accumulate else 0, _lib.stream_ptr(x1.device)))
     return partials
 
 
-def wgrad_unpack_batch(dWts):
-    """[(9,cout,cin) | (slices,9,cout,cin), ...] -> [(cout,cin,3,3), ...] (views of one buffer) in one
-    launch; 4-d entries are per-workgroup partial sums and are summed over their first axis."""
-    n = len(dWts)
-    slices = [d.shape[0] if d.dim() == 4 else 0 for d in dWts]
-    dWts_in = dWts
-    dWts = [d[0] if d.dim() == 4 else d for d in dWts]          # (9,cout,cin) shapes
-    sizes = [d.numel() for d in dWts]
+def wgrad_unpack_batch(items):
+    """One launch for a list of layers.  Each item is either a (9,cout,cin) tensor (atomic form) or a tuple
+    (partials, cout, cin[, db_out]) of the partial-sum form; returns the (cout,cin,3,3) gradients (views of
+    one buffer); bias sums of the partial form are written to db_out (cout,) when given."""
+    n = len(items)
+    srcs, couts, cins, slices, dbs = [], [], [], [], []
+    for it in items:
+        if isinstance(it, (tuple, list)):
+            t, co, ci = it[0], it[1], it[2]
+            srcs.append(t); couts.append(co); cins.append(ci); slices.append(t.shape[0])
+            dbs.append(it[3] if len(it) > 3 else None)
+        else:
+            srcs.append(it); couts.append(it.shape[1]); cins.append(it.shape[2]); slices.append(0); dbs.append(None)
+    sizes = [9 * co * ci for co, ci in zip(couts, cins)]
     offs = [0]
     for sz in sizes:
         offs.append(offs[-1] + (sz + 3) // 4 * 4)
-    buf = torch.empty(offs[-1], dtype=torch.float32, device=dWts[0].device)
+    dev = srcs[0].device
+    buf = torch.empty(offs[-1], dtype=torch.float32, device=dev)
     base = buf.data_ptr()
-    Sp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dWts_in])
+    Sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
     Op = (ctypes.c_void_p * n)(*[base + 4 * o for o in offs[:-1]])
+    Dp = (ctypes.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in dbs])
     sl = (ctypes.c_int32 * n)(*slices)
-    co = (ctypes.c_int32 * n)(*[d.shape[1] for d in dWts])
-    ci = (ctypes.c_int32 * n)(*[d.shape[2] for d in dWts])
-    _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack_batch(n, Sp, sl, co, ci, Op, _lib.stream_ptr(dWts[0].device)))
-    return [buf[offs[i]:offs[i] + sizes[i]].view(dWts[i].shape[1], dWts[i].shape[2], 3, 3) for i in range(n)]
+    co = (ctypes.c_int32 * n)(*couts)
+    ci = (ctypes.c_int32 * n)(*cins)
+    _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack_batch(n, Sp, sl, co, ci, Op, Dp, _lib.stream_ptr(dev)))
+    return [buf[offs[i]:offs[i] + sizes[i]].view(couts[i], cins[i], 3, 3) for i in range(n)]
 
 
 # ----------------------------------------------------------------------------- small wrappers
@@ -314,7 +327,7 @@ class _UNet(torch.autograd.Function):
         def grads(k):
             return dWt[k], dB[k]
 
-        part = {}        # layer -> (slices,9,cout,cin) partial sums (the layers with >= 64 channels)
+        part = {}        # layer -> partial-sum slices (weights + bias)
 
         def wgrad(k, x1, g, x2=None):
             dw, db = grads(k)
@@ -323,8 +336,8 @@ class _UNet(torch.autograd.Function):
             if ns > 0:
                 first = k not in part
                 if first:
-                    part[k] = torch.empty(ns, 9, cout_k, cin_k, dtype=torch.float32, device=dev)
-                conv3x3_wgrad_partial(x1, g, cout_k, part[k], x2=x2, db=db, accumulate=not first)
+                    part[k] = partial_buffer(ns, cout_k, cin_k, dev)
+                conv3x3_wgrad_partial(x1, g, cout_k, part[k], x2=x2, accumulate=not first)
             else:
                 conv3x3_wgrad(x1, g, cout_k, x2=x2, dWt=dw, db=db)
 
@@ -395,7 +408,8 @@ class _UNet(torch.autograd.Function):
         _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0), _sp(dev)))
         # ---- assemble parameter gradients in input order
         out = [g_w0, g_b0]
-        for k, gw in zip(range(1, 22), wgrad_unpack_batch([part.get(k, dWt[k]) for k in range(1, 22)])):
+        items = [(part[k], W(k).shape[0], W(k).shape[1], dB[k]) if k in part else dWt[k] for k in range(1, 22)]
+        for k, gw in zip(range(1, 22), wgrad_unpack_batch(items)):
             out += [gw, dB[k]]
         out += [g_fw.reshape(1, 8, 1, 1), g_fb]
         out = [g.to(p.dtype) for g, p in zip(out, P)]

@@ -25,7 +25,7 @@ for cin, cout, H in [(8, 8, 640), (16, 16, 640), (128, 128, 80)]:
     y = torch.empty(B, H, H, cout, dtype=torch.bfloat16, device=dev)
     o = torch.empty(B, H, H, cin, dtype=torch.bfloat16, device=dev)
     ns = uh.wgrad_slices(cout, cin, cin, B, H, H)
-    part = torch.empty(ns, 9, cout, cin, device=dev)
+    part = uh.partial_buffer(ns, cout, cin, dev)
     for _ in range(reps):
         uh.conv3x3(x, wp, cout, bias=b, relu=True, drop_p=0.05, seed=1, out=y)
         uh.conv3x3(g, wpt, cin, out=o, relu_src=x, scale=1.05)

@@ -135,25 +135,27 @@ def test_conv3x3_wgrad(cin, cout, H, W):
     dWt2 = uh.conv3x3_wgrad(x, gy, cout, dWt=dWt.clone())
     acc = uh.wgrad_unpack(dWt2, accumulate_into=torch.ones_like(dW))
     assert (acc - (2 * w.grad + 1)).abs().max().item() < 4e-3 * scale + 2e-3
-    # partial-sum form (no float atomics) where the library offers it; two applications accumulate
+    # partial-sum form (no float atomics): weights and bias, two applications accumulate
     ns = uh.wgrad_slices(cout, cin, cin, B, H, W)
     assert ns > 0
-    if ns > 0:
-        part = torch.full((ns, 9, cout, cin), float("nan"), device=DEV)      # must be fully overwritten
-        db2 = torch.zeros(cout, device=DEV)
-        uh.conv3x3_wgrad_partial(x, gy, cout, part, db=db2)
-        dWp, dWs = uh.wgrad_unpack_batch([part, dWt])
-        assert (dWp - w.grad).abs().max().item() < 2e-3 * scale + 1e-3
-        assert torch.equal(dWs, dW)
-        assert (db2 - bias.grad).abs().max().item() < 2e-3 * bias.grad.abs().max().item() + 1e-3
-        uh.conv3x3_wgrad_partial(x, gy, cout, part, accumulate=True)
-        (dWp2,) = uh.wgrad_unpack_batch([part])
-        assert (dWp2 - 2 * w.grad).abs().max().item() < 4e-3 * scale + 2e-3
-        # bit-reproducible: same inputs, same bits
-        part_b = torch.empty_like(part)
-        uh.conv3x3_wgrad_partial(x, gy, cout, part_b)
-        uh.conv3x3_wgrad_partial(x, gy, cout, part_b, accumulate=True)
-        assert torch.equal(uh.wgrad_unpack_batch([part_b])[0], dWp2)
+    part = torch.full((ns, 9 * cout * cin + cout), float("nan"), device=DEV)      # must be fully overwritten
+    db2 = torch.zeros(cout, device=DEV)
+    uh.conv3x3_wgrad_partial(x, gy, cout, part)
+    dWp, dWs = uh.wgrad_unpack_batch([(part, cout, cin, db2), dWt])
+    assert (dWp - w.grad).abs().max().item() < 2e-3 * scale + 1e-3
+    assert torch.equal(dWs, dW)
+    assert (db2 - bias.grad).abs().max().item() < 2e-3 * bias.grad.abs().max().item() + 1e-3
+    uh.conv3x3_wgrad_partial(x, gy, cout, part, accumulate=True)
+    db3 = torch.zeros(cout, device=DEV)
+    (dWp2,) = uh.wgrad_unpack_batch([(part, cout, cin, db3)])
+    assert (dWp2 - 2 * w.grad).abs().max().item() < 4e-3 * scale + 2e-3
+    assert (db3 - 2 * bias.grad).abs().max().item() < 4e-3 * bias.grad.abs().max().item() + 2e-3
+    # bit-reproducible: same inputs, same bits
+    part_b = torch.empty_like(part)
+    uh.conv3x3_wgrad_partial(x, gy, cout, part_b)
+    uh.conv3x3_wgrad_partial(x, gy, cout, part_b, accumulate=True)
+    db4 = torch.zeros(cout, device=DEV)
+    assert torch.equal(uh.wgrad_unpack_batch([(part_b, cout, cin, db4)])[0], dWp2) and torch.equal(db4, db3)
 
 
 def test_conv3x3_wgrad_concat():
