@@ -1680,11 +1680,12 @@ struct UnpackBatch {
     int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX], slices[PACK_BATCH_MAX];
 };
 
-// One block = 32 consecutive elements of a slice x 8 groups of slices: coalesced 128-byte reads of every
-// slice, LDS sum over the groups; weight sums go transposed to [co][ci][tap], bias sums to db.
+// One block = 256 consecutive elements of a slice (64 lanes x float4: 1 KB contiguous per wave and
+// slice) x 4 groups of slices, LDS sum over the groups; weight sums go transposed to [co][ci][tap], bias
+// sums to db.  (Slice strides are multiples of 4 floats only when cout is: the tail is read scalar.)
 __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch ub)
 {
-    __shared__ float red[8][33];
+    __shared__ float red[4][256 + 4];
     const int l = blockIdx.y;
     const int COUT = ub.cout[l], CIN = ub.cin[l];
     const int nw = COUT * CIN * 9;
@@ -1694,23 +1695,35 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
     const float *__restrict__ src = ub.src[l];
     float *__restrict__ dst = ub.dW[l];
     float *__restrict__ dbo = ub.db[l];
-    const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    for (int e0 = blockIdx.x * 32; e0 < total; e0 += gridDim.x * 32) {
-        const int e = e0 + el;
-        float v = 0.f;
-        if (e < total)
-            for (int sl = sg; sl < S; sl += 8) v += src[(size_t)sl * total + e];
-        red[sg][el] = v;
-        __syncthreads();
-        if (sg == 0 && e < total) {
-            float t = 0.f;
+    const int ln = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const bool vec = (total & 3) == 0;                // float4 path: slices stay 16-byte aligned
+    for (int e0 = blockIdx.x * 256; e0 < total; e0 += gridDim.x * 256) {
+        const int e = e0 + 4 * ln;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && e + 3 < total) {
+            for (int sl = sg; sl < S; sl += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)sl * total + e);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+        } else {
+            for (int sl = sg; sl < S; sl += 4)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k][el];
-            if (e < nw) {
-                const int ci = e % CIN, co = (e / CIN) % COUT, tap = e / (CIN * COUT);
-                dst[((size_t)co * CIN + ci) * 9 + tap] = t;
-            } else if (dbo) {
-                dbo[e - nw] = t;
+                for (int j = 0; j < 4; ++j)
+                    if (e + j < total) v[j] += src[(size_t)sl * total + e + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[sg][4 * ln + j] = v[j];
+        __syncthreads();
+        {
+            const int ee = e0 + threadIdx.x;
+            if (ee < total) {
+                const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+                if (ee < nw) {
+                    const int ci = ee % CIN, co = (ee / CIN) % COUT, tap = ee / (CIN * COUT);
+                    dst[((size_t)co * CIN + ci) * 9 + tap] = t;
+                } else if (dbo) {
+                    dbo[ee - nw] = t;
+                }
             }
         }
         __syncthreads();
@@ -2282,7 +2295,7 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
             ub.db[i] = (db && ub.slices[i] > 0) ? db[k] : nullptr;
             most = std::max(most, cout[k] * cin[k] * 9 + cout[k]);
         }
-        const unsigned bx = (unsigned)std::min((most + 31) / 32, 2048);
+        const unsigned bx = (unsigned)std::min((most + 255) / 256, 1024);
         hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
         MMK_LAUNCH_CHECK();
     }
