@@ -66,6 +66,44 @@ def test_conv3x3_many_tiles_per_block(cin, cout):
     assert (o.float() - want).abs().max().item() < 0.06
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128), (256, 128), (32, 64), (64, 32), (64, 192), (128, 16)])
+def test_conv3x3_deep_kernel_wide_rows(cin, cout):
+    """The >= 64-channel kernel on 80-pixel rows (its 5-tile-wide variant; the other shape tests stay
+    below 48 pixels and take the 3-tile one): forward, concatenated input, split output with ReLU source
+    and accumulation through the lane-group-swapped epilogue, and a channel count (192) whose last block
+    of 128 is only half there."""
+    B, H, W = 2, 12, 80
+    x = _rand_nhwc(B, H, W, cin, 3 * cin + cout)
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    wp = uh.pack_weights(w)
+    ref = _ref_conv(x, w, b, True)
+    y = uh.conv3x3(x, wp, cout, bias=b, relu=True)
+    assert (y.float() - ref).abs().max().item() < 0.03
+    # concatenated input
+    h = cin // 2
+    if h % 32 == 0:
+        y2 = uh.conv3x3(x[..., :h].contiguous(), wp, cout, bias=b, x2=x[..., h:].contiguous(), relu=True)
+        assert torch.equal(y2, y)
+    # split output: first part accumulates, second part gets a ReLU-backward factor
+    if cout % 32 == 0 and cout >= 64:
+        s1 = cout // 2
+        ref2 = _ref_conv(x, w, None, False)
+        base = _rand_nhwc(B, H, W, s1, 41)
+        src = _rand_nhwc(B, H, W, cout - s1, 42)
+        o1, o2 = uh.conv3x3(x, wp, cout, split=s1, out=base.clone(), accumulate=True, relu_src2=src, scale2=1.25)
+        assert (o1.float() - (base.float() + ref2[..., :s1])).abs().max().item() < 0.06
+        want2 = torch.where(src.float() > 0, ref2[..., s1:] * 1.25, torch.zeros_like(ref2[..., s1:]))
+        assert (o2.float() - want2).abs().max().item() < 0.05
+        # single output, ReLU source + accumulate together (the data-gradient form of the encoder)
+        srcf = _rand_nhwc(B, H, W, cout, 43)
+        basef = _rand_nhwc(B, H, W, cout, 44)
+        o = uh.conv3x3(x, wp, cout, out=basef.clone(), accumulate=True, relu_src=srcf, scale=0.75)
+        want = basef.float() + torch.where(srcf.float() > 0, ref2 * 0.75, torch.zeros_like(ref2))
+        assert (o.float() - want).abs().max().item() < 0.06
+
+
 def test_conv3x3_concat_split_accumulate_relu_src():
     B, H, W = 2, 24, 40
     xa, xb = _rand_nhwc(B, H, W, 8, 1), _rand_nhwc(B, H, W, 8, 2)
@@ -156,6 +194,27 @@ def test_conv3x3_wgrad(cin, cout, H, W):
     uh.conv3x3_wgrad_partial(x, gy, cout, part_b, accumulate=True)
     db4 = torch.zeros(cout, device=DEV)
     assert torch.equal(uh.wgrad_unpack_batch([(part_b, cout, cin, db4)])[0], dWp2) and torch.equal(db4, db3)
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 8), (32, 32), (64, 64)])
+def test_conv3x3_wgrad_many_tiles_per_block(cin, cout):
+    """Enough tiles that every persistent workgroup of the weight-gradient kernels walks several of its
+    XCD's range (partial-sum form), against the fp32 reference."""
+    B, H, W = 4, 256, 288
+    x = _rand_nhwc(B, H, W, cin, 5 * cin + cout)
+    gy = (_rand_nhwc(B, H, W, cout, 6 * cin + cout).float() / 16).to(torch.bfloat16)
+    w = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    bias = torch.zeros(cout, device=DEV, requires_grad=True)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=1)
+    y.backward(gy.float().permute(0, 3, 1, 2))
+    ns = uh.wgrad_slices(cout, cin, cin, B, H, W)
+    part = uh.partial_buffer(ns, cout, cin, DEV)
+    uh.conv3x3_wgrad_partial(x, gy, cout, part)
+    db = torch.zeros(cout, device=DEV)
+    (dW,) = uh.wgrad_unpack_batch([(part, cout, cin, db)])
+    scale = w.grad.abs().max().item()
+    assert (dW - w.grad).abs().max().item() < 2e-3 * scale + 1e-3
+    assert (db - bias.grad).abs().max().item() < 2e-3 * bias.grad.abs().max().item() + 1e-3
 
 
 def test_conv3x3_wgrad_concat():
