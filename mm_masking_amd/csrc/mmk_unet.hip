@@ -418,30 +418,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Loads / stores / waits that hipcc does not see.  In the kernels without epilogue operands every
-// vector-memory instruction of the steady-state loop is one of these, the number of instructions
-// between a tile's loads and their use is a compile-time constant, and the wait before the LDS
-// write is the exact s_waitcnt vmcnt(N) that leaves the RD-1 younger tiles in flight (hipcc's own
-// bookkeeping settles for N ~ one stage: DESIGN.md 5b).
-__device__ __forceinline__ u32x4 asm_load16(const u32x4 *p)
-{
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-__device__ __forceinline__ void asm_store8(void *p, unsigned long long v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void asm_wait_vmcnt()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
-}
-
 template <int CK, int CM, int RD, bool EPI>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
@@ -454,7 +430,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr bool MAN = !EPI;                                 // hand-counted vmcnt (see asm_load16)
     constexpr int NST = MT * NT;                               // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
@@ -547,8 +522,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
             const bool ok = (unsigned)(ty0_ + g_dy[i]) < (unsigned)a.H && (unsigned)(tx0_ + g_dx[i]) < (unsigned)a.W; \
             const bf16 *src = (in_x2[i] ? base2_ : base1_) + in_off[i];                                      \
             const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16;                         \
-            if constexpr (MAN) rin[SLOT][i] = asm_load16(sp);                                                \
-            else rin[SLOT][i] = *sp;                                                                         \
+            rin[SLOT][i] = *sp;                                                                              \
         }                                                                                                    \
         /* next tile of the walk (parks on the block's last tile: the ring keeps re-loading it) */           \
         const bool adv_ = ld_left > 0;                                                                       \
@@ -565,10 +539,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     }
 #define MMK_RING_SINKS()                                                                                     \
     {                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < NST; ++i) {                                                    \
-            if constexpr (MAN) asm_store8(g_sink16, 0ull);                                                   \
-            else reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull;                                 \
-        }                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NST; ++i) reinterpret_cast<unsigned long long *>(g_sink16)[i] = 0ull; \
     }
 #define MMK_RING_STORE(SLOT, BUF)                                                                            \
     {                                                                                                        \
@@ -614,7 +585,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
         MMK_RING_LOAD(2);
         MMK_RING_SINKS();
     }
-    if constexpr (MAN) asm_wait_vmcnt<(RD - 1) * (RIN + NST)>();
     cur_pix0 = s_pix0[0]; cur_ty0 = s_ty0[0]; cur_tx0 = s_tx0[0];
     MMK_RING_STORE(0, 0);
     MMK_RING_LOAD(0);
