@@ -283,17 +283,18 @@ def test_aux_kernels_vs_torch():
     want = (dref.grad * (dref > 0) * 1.25).permute(0, 2, 3, 1)
     assert (gz.float() - want).abs().max().item() < 0.02
     # bilinear upsample (align_corners) fwd / bwd
-    for (hs, ws, ho, wo) in [(20, 20, 40, 40), (5, 7, 10, 14), (40, 40, 80, 80), (6, 6, 13, 11), (3, 4, 30, 44)]:
-        xs = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
+    for (hs, ws, ho, wo, ch) in [(20, 20, 40, 40, 8), (5, 7, 10, 14, 8), (40, 40, 80, 80, 8), (6, 6, 13, 11, 8), (3, 4, 30, 44, 8),
+                                 (20, 24, 40, 48, 16), (12, 20, 24, 40, 32), (9, 10, 18, 20, 64), (5, 5, 10, 10, 128)]:
+        xs = torch.randn(2, ch, hs, ws, generator=g).to(DEV)
         xr = xs.to(torch.bfloat16).float().requires_grad_(True)
         ur = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=True)
         u = uh.upsample(_nhwc(xs), ho, wo)
         assert (u.float() - ur.permute(0, 2, 3, 1)).abs().max().item() < 0.02
-        gu = torch.randn(2, 8, ho, wo, generator=g).to(DEV)
+        gu = torch.randn(2, ch, ho, wo, generator=g).to(DEV)
         ur.backward(gu.to(torch.bfloat16).float())
         gx = uh.upsample_bwd(_nhwc(gu), hs, ws)
         assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.05 + 0.008 * xr.grad.abs().max().item()   # bf16 output
-        src = torch.randn(2, 8, hs, ws, generator=g).to(DEV)
+        src = torch.randn(2, ch, hs, ws, generator=g).to(DEV)
         gx2 = uh.upsample_bwd(_nhwc(gu), hs, ws, relu_src=_nhwc(src), scale=2.0)
         want = (xr.grad * (src.to(torch.bfloat16).float() > 0) * 2.0).permute(0, 2, 3, 1)
         assert (gx2.float() - want).abs().max().item() < 0.1 + 0.008 * want.abs().max().item()
