@@ -392,13 +392,15 @@ def _unet_on_hip_activations(model, x, fwd, drop=0.0):
     return torch.sigmoid(F.conv2d(cur, fl.weight.to(torch.bfloat16).float(), fl.bias)).squeeze(1)
 
 
-@pytest.mark.parametrize("H,drop", [(64, 0.0), (160, 0.0), (96, 0.1)])
-def test_unet_hip_backward_exact_on_pinned_activations(H, drop):
+@pytest.mark.parametrize("B,H,W,drop", [(2, 64, 64, 0.0), (2, 160, 160, 0.0), (2, 96, 96, 0.1), (3, 64, 160, 0.05), (1, 320, 96, 0.0)])
+def test_unet_hip_backward_exact_on_pinned_activations(B, H, W, drop):
+    """Whole network, forward + all 46 parameter gradients, against autograd on the activations the HIP
+    path produced (square and non-square images, batch sizes that are not multiples of the XCD count)."""
     model = _policy(drop, torch.float32)
     model.train()
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(2, 1, H, H, generator=g).to(DEV)
-    gsel = torch.randn(2, H, H, generator=g).to(DEV)
+    x = torch.rand(B, 1, H, W, generator=g).to(DEV)
+    gsel = torch.randn(B, H, W, generator=g).to(DEV)
     uh.DEBUG = {}
     try:
         out = uh.unet_mask(model, x, training=True, seed=5)
