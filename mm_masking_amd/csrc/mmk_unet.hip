@@ -655,8 +655,11 @@ template <int CK, int CM>
 int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
 {
     constexpr int RD = CK <= 16 ? 3 : 2;
+    // with epilogue operands the in-order load queue keeps ~1 tile in flight whatever the ring holds:
+    // two slots there, and the registers go to occupancy
+    constexpr int RDE = 2;
     const bool epi = a.o1.relu_src || a.o1.accumulate || (a.o2.C > 0 && (a.o2.relu_src || a.o2.accumulate));
-    return epi ? launch_conv_ring<CK, CM, RD, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
+    return epi ? launch_conv_ring<CK, CM, RDE, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
 }
 
 
