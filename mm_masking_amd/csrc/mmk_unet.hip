@@ -32,7 +32,17 @@ constexpr int CONV_THREADS = 256;
 
 // LDS pixel pitch (elements): 16 bytes of padding de-correlates the banks of consecutive
 // pixels for the 16-byte fragment reads (a 128-byte pitch is an 8-way conflict).
-__host__ __device__ constexpr int lds_pitch(int c) { return c >= 16 ? c + 8 : c; }
+// LDS pixel pitch (elements) of the conv kernels' halo tiles.  A B fragment is a ds_read_b128 whose 64
+// lanes are served in four groups of 16 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: MI355X_MICROARCH.md,
+// LDS): lane l reads pixel l%16, 16-byte granule l/16.  Enumerating those groups, the read is
+// conflict-free exactly when the pitch is 2 (mod 4) granules of 16 bytes: 16 elements unpadded, 32 -> 48,
+// 64 -> 80; the pitches c + 8 cost 2x there (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  The
+// 16-channel tiles are therefore unpadded and the >= 64-channel kernel uses 48; the 4-wave kernels keep
+// 40 for 32 channels (48 would cost them a resident block per CU, and they are not LDS-bound).
+// 8-channel tiles (1 granule per pixel) are conflict-free as they are.
+__host__ __device__ constexpr int lds_pitch(int c) { return c >= 32 ? c + 8 : c; }
+// weight-gradient tiles (read with ds_read_b64_tr_b16: different lane grouping, see there)
+__host__ __device__ constexpr int wg_pitch(int c) { return c >= 16 ? c + 8 : c; }
 __host__ __device__ constexpr int ksteps(int ck) { return ck >= 32 ? 9 * (ck / 32) : (ck == 16 ? 5 : 3); }
 // weight-gradient kernel: input-channel chunk / output-channel group of one block
 __host__ __device__ constexpr int cin_chunk(int cin) { return cin >= 64 ? 64 : cin; }
@@ -679,7 +689,7 @@ struct DeepCfg {
     static constexpr int MTB = BM / 16;                   // ... per block
     static constexpr int TH = WN, TWD = NT * 16;
     static constexpr int HT = TH + 2, WT = TWD + 2;
-    static constexpr int CK = 32, PK = 40, NS = 9, GPP = 4;
+    static constexpr int CK = 32, PK = 48, NS = 9, GPP = 4;
     static constexpr int NIN = HT * WT * GPP;
     static constexpr int NW = NS * MTB * 64;
     static constexpr int RIN = (NIN + DEEP_THREADS - 1) / DEEP_THREADS;
@@ -1105,9 +1115,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     constexpr int NTT = (CK >= 16) ? 9 * (CK / 16) : 5;  // n-tiles of 16 (tap, ci) columns
     constexpr int NTW = (NTT + 3) / 4;                    // per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PK = lds_pitch(CK);
+    constexpr int PK = wg_pitch(CK);
     constexpr int GCOLS = G8 ? 8 : CM;                    // channels of the g tile
-    constexpr int PG = lds_pitch(GCOLS);
+    constexpr int PG = wg_pitch(GCOLS);
     bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // HT*WT*PK (+ pad)
     bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // TH*TW*PG (+ pad)
 
@@ -1323,7 +1333,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 template <int CK, int CM, bool G8>
 int wgrad_spatial(int cout, int cin, int B, int H, int W)
 {
-    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(G8 ? 8 : CM)) * sizeof(bf16);
+    const size_t smem = ((size_t)(HT * WT + 8) * wg_pitch(CK) + (size_t)(TH * TW + 8) * wg_pitch(G8 ? 8 : CM)) * sizeof(bf16);
     static int per_cu[64] = {};      // resident blocks per CU (registers / LDS), per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -1346,7 +1356,7 @@ int wgrad_spatial(int cout, int cin, int B, int H, int W)
 template <int CK, int CM, bool G8>
 int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
-    const size_t smem = ((size_t)(HT * WT + 8) * lds_pitch(CK) + (size_t)(TH * TW + 8) * lds_pitch(G8 ? 8 : CM)) * sizeof(bf16);
+    const size_t smem = ((size_t)(HT * WT + 8) * wg_pitch(CK) + (size_t)(TH * TW + 8) * wg_pitch(G8 ? 8 : CM)) * sizeof(bf16);
     const int spatial = wgrad_spatial<CK, CM, G8>(a.COUT, a.CIN, a.B, a.H, a.W);
     if (spatial < 1) {
         mmk::set_error("mmk_conv3x3_wgrad: occupancy query failed");
