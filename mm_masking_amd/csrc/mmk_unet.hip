@@ -42,7 +42,12 @@ constexpr int CONV_THREADS = 256;
 // 8-channel tiles (1 granule per pixel) are conflict-free as they are.
 __host__ __device__ constexpr int lds_pitch(int c) { return c >= 32 ? c + 8 : c; }
 // weight-gradient tiles (read with ds_read_b64_tr_b16: different lane grouping, see there)
-__host__ __device__ constexpr int wg_pitch(int c) { return c >= 16 ? c + 8 : c; }
+// A 16-lane group of a transposing read fetches 4 consecutive pixels x 32 bytes (16 channels), and the LDS
+// serves it in two groups of 32 lanes.  With the k index of the MFMA mapped to pixels so that a group of 32
+// lanes covers 8 *consecutive* pixels (lane group g, first/second read: pixels 4g+q / 16+4g+q), the read is
+// conflict-free when the pixel pitch is 16 (mod 32) elements: 16 unpadded, 32 -> 48, 64 -> 80 (the old
+// mapping, pixels 8g+q, conflicted 2-way at every pitch but 8).
+__host__ __device__ constexpr int wg_pitch(int c) { return c >= 32 ? c + 16 : c; }
 __host__ __device__ constexpr int ksteps(int ck) { return ck >= 32 ? 9 * (ck / 32) : (ck == 16 ? 5 : 3); }
 // weight-gradient kernel: input-channel chunk / output-channel group of one block
 __host__ __device__ constexpr int cin_chunk(int cin) { return cin >= 64 ? 64 : cin; }
@@ -1157,9 +1162,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         }
         tap = tap > 8 ? 8 : tap;
         const int ty = tap / 3, tx = tap % 3;
-        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 8 * g4 + q + tx) * PK + col) * 2);
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PK + col) * 2);
     }
-    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((8 * g4 + q) * PG + 4 * pp) * 2);
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((4 * g4 + q) * PG + 4 * pp) * 2);
 
     // register prefetch of the next tile's operands while the current one is consumed; every load
     // is unconditional (out-of-image granules read the zero word)
@@ -1250,14 +1255,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
                            : (m == 1) ? tr_read_o<((R) * TW * PG + 16) * 2>(g_ad)                        \
                            : (m == 2) ? tr_read_o<((R) * TW * PG + 32) * 2>(g_ad)                        \
                                       : tr_read_o<((R) * TW * PG + 48) * 2>(g_ad);                       \
-            fa[BUF][2 * m + 1] = (m == 0) ? tr_read_o<((R) * TW * PG + 4 * PG) * 2>(g_ad)                \
-                               : (m == 1) ? tr_read_o<((R) * TW * PG + 16 + 4 * PG) * 2>(g_ad)           \
-                               : (m == 2) ? tr_read_o<((R) * TW * PG + 32 + 4 * PG) * 2>(g_ad)           \
-                                          : tr_read_o<((R) * TW * PG + 48 + 4 * PG) * 2>(g_ad);          \
+            fa[BUF][2 * m + 1] = (m == 0) ? tr_read_o<((R) * TW * PG + 16 * PG) * 2>(g_ad)                \
+                               : (m == 1) ? tr_read_o<((R) * TW * PG + 16 + 16 * PG) * 2>(g_ad)           \
+                               : (m == 2) ? tr_read_o<((R) * TW * PG + 32 + 16 * PG) * 2>(g_ad)           \
+                                          : tr_read_o<((R) * TW * PG + 48 + 16 * PG) * 2>(g_ad);          \
         }                                                                                                \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                                \
             fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                                    \
-            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 4 * PK) * 2>(b_ad[n]);                       \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(b_ad[n]);                       \
         }                                                                                                \
     }
 #define WG_CONSUME(BUF)                                                                                  \
@@ -1380,7 +1385,7 @@ constexpr int WGD_THREADS = 512;
 
 __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const WgradArgs a)
 {
-    constexpr int CK = 64, CM = 64, PK = 72, PG = 72;
+    constexpr int CK = 64, CM = 64, PK = wg_pitch(64), PG = wg_pitch(64);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *x_tile = reinterpret_cast<bf16 *>(smem);                 // (HT*WT + 8) * PK
     bf16 *g_tile = x_tile + (HT * WT + 8) * PK;                    // (TH*TW + 8) * PG
@@ -1408,8 +1413,8 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
 
-    const unsigned xb0 = lds_addr(x_tile) + (unsigned)(((8 * g4 + q) * PK + wc * 16 + 4 * pp) * 2);
-    const unsigned gb0 = lds_addr(g_tile) + (unsigned)(((8 * g4 + q) * PG + wm * 32 + 4 * pp) * 2);
+    const unsigned xb0 = lds_addr(x_tile) + (unsigned)(((4 * g4 + q) * PK + wc * 16 + 4 * pp) * 2);
+    const unsigned gb0 = lds_addr(g_tile) + (unsigned)(((4 * g4 + q) * PG + wm * 32 + 4 * pp) * 2);
 
     // register staging of the next tile (same scheme as conv3x3_wgrad_kernel)
     constexpr int GPP = CK / 8;
@@ -1498,17 +1503,17 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
 #define WGD_ISSUE(RHO)                                                                                   \
     {                                                                                                    \
         fb[0][0] = tr_read_o<(((RHO) * WT + 0) * PK) * 2>(xb0);                                          \
-        fb[0][1] = tr_read_o<(((RHO) * WT + 0) * PK + 4 * PK) * 2>(xb0);                                 \
+        fb[0][1] = tr_read_o<(((RHO) * WT + 0) * PK + 16 * PK) * 2>(xb0);                                 \
         fb[1][0] = tr_read_o<(((RHO) * WT + 1) * PK) * 2>(xb0);                                          \
-        fb[1][1] = tr_read_o<(((RHO) * WT + 1) * PK + 4 * PK) * 2>(xb0);                                 \
+        fb[1][1] = tr_read_o<(((RHO) * WT + 1) * PK + 16 * PK) * 2>(xb0);                                 \
         fb[2][0] = tr_read_o<(((RHO) * WT + 2) * PK) * 2>(xb0);                                          \
-        fb[2][1] = tr_read_o<(((RHO) * WT + 2) * PK + 4 * PK) * 2>(xb0);                                 \
+        fb[2][1] = tr_read_o<(((RHO) * WT + 2) * PK + 16 * PK) * 2>(xb0);                                 \
         if ((RHO) < TH) {                                                                                \
             constexpr int R_ = (RHO) < TH ? (RHO) : 0;                                                   \
             fa[R_ % 3][0][0] = tr_read_o<((R_ * TW) * PG) * 2>(gb0);                                     \
-            fa[R_ % 3][0][1] = tr_read_o<((R_ * TW) * PG + 4 * PG) * 2>(gb0);                            \
+            fa[R_ % 3][0][1] = tr_read_o<((R_ * TW) * PG + 16 * PG) * 2>(gb0);                            \
             fa[R_ % 3][1][0] = tr_read_o<((R_ * TW) * PG + 16) * 2>(gb0);                                \
-            fa[R_ % 3][1][1] = tr_read_o<((R_ * TW) * PG + 16 + 4 * PG) * 2>(gb0);                       \
+            fa[R_ % 3][1][1] = tr_read_o<((R_ * TW) * PG + 16 + 16 * PG) * 2>(gb0);                       \
         }                                                                                                \
     }
 #define WGD_STEP(RHO)                                                                                    \
@@ -1602,7 +1607,7 @@ bool wgrad_is_deep(int cout, int cin, int c1) { return use_wgrad_deep() && cin %
 
 int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
 {
-    const size_t smem = ((size_t)(HT * WT + 8) * 72 + (size_t)(TH * TW + 8) * 72) * sizeof(bf16);
+    const size_t smem = ((size_t)(HT * WT + 8) * wg_pitch(64) + (size_t)(TH * TW + 8) * wg_pitch(64)) * sizeof(bf16);
     static bool attr_set[64] = {};
     int dev = 0;
     MMK_CHECK_HIP(hipGetDevice(&dev));
