@@ -1494,47 +1494,45 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
             const int nt = t + t_step;
             load_tile(nt < t_end ? nt : t);       // (clamped: the loads stay unconditional)
         }
-        // fragment registers: x row rho in fb, g rows rho-2 .. rho in a ring of 3.  The reads of row
-        // rho+1 are issued right behind row rho's MFMAs (which have read their operands by then) and
-        // land while the matrix pipe works through them / the SIMD's other wave runs.  Every read
-        // carries its offset as an immediate: ~100 distinct addresses would otherwise be hoisted
-        // into registers and spilled.
-        i32x2 fb[3][2], fa[3][2][2];
+        // double-buffered fragment registers; every read carries its offset as an immediate (~100 distinct
+        // addresses would otherwise be hoisted into registers and spilled)
+        i32x2 fb[2][3][2], fa[4][2][2];      // x row rho in fb[rho & 1]; g rows rho-2 .. rho+1 in a ring of 4
 #define WGD_ISSUE(RHO)                                                                                   \
     {                                                                                                    \
-        fb[0][0] = tr_read_o<(((RHO) * WT + 0) * PK) * 2>(xb0);                                          \
-        fb[0][1] = tr_read_o<(((RHO) * WT + 0) * PK + 16 * PK) * 2>(xb0);                                 \
-        fb[1][0] = tr_read_o<(((RHO) * WT + 1) * PK) * 2>(xb0);                                          \
-        fb[1][1] = tr_read_o<(((RHO) * WT + 1) * PK + 16 * PK) * 2>(xb0);                                 \
-        fb[2][0] = tr_read_o<(((RHO) * WT + 2) * PK) * 2>(xb0);                                          \
-        fb[2][1] = tr_read_o<(((RHO) * WT + 2) * PK + 16 * PK) * 2>(xb0);                                 \
+        fb[(RHO) & 1][0][0] = tr_read_o<(((RHO) * WT + 0) * PK) * 2>(xb0);                               \
+        fb[(RHO) & 1][0][1] = tr_read_o<(((RHO) * WT + 0) * PK + 16 * PK) * 2>(xb0);                     \
+        fb[(RHO) & 1][1][0] = tr_read_o<(((RHO) * WT + 1) * PK) * 2>(xb0);                               \
+        fb[(RHO) & 1][1][1] = tr_read_o<(((RHO) * WT + 1) * PK + 16 * PK) * 2>(xb0);                     \
+        fb[(RHO) & 1][2][0] = tr_read_o<(((RHO) * WT + 2) * PK) * 2>(xb0);                               \
+        fb[(RHO) & 1][2][1] = tr_read_o<(((RHO) * WT + 2) * PK + 16 * PK) * 2>(xb0);                     \
         if ((RHO) < TH) {                                                                                \
             constexpr int R_ = (RHO) < TH ? (RHO) : 0;                                                   \
-            fa[R_ % 3][0][0] = tr_read_o<((R_ * TW) * PG) * 2>(gb0);                                     \
-            fa[R_ % 3][0][1] = tr_read_o<((R_ * TW) * PG + 16 * PG) * 2>(gb0);                            \
-            fa[R_ % 3][1][0] = tr_read_o<((R_ * TW) * PG + 16) * 2>(gb0);                                \
-            fa[R_ % 3][1][1] = tr_read_o<((R_ * TW) * PG + 16 + 16 * PG) * 2>(gb0);                       \
+            fa[R_ & 3][0][0] = tr_read_o<((R_ * TW) * PG) * 2>(gb0);                                     \
+            fa[R_ & 3][0][1] = tr_read_o<((R_ * TW) * PG + 16 * PG) * 2>(gb0);                           \
+            fa[R_ & 3][1][0] = tr_read_o<((R_ * TW) * PG + 16) * 2>(gb0);                                \
+            fa[R_ & 3][1][1] = tr_read_o<((R_ * TW) * PG + 16 + 16 * PG) * 2>(gb0);                      \
         }                                                                                                \
     }
 #define WGD_STEP(RHO)                                                                                    \
     {                                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
         __builtin_amdgcn_sched_barrier(0);                                                               \
+        /* row rho+1 is fetched while row rho is on the matrix cores */                                  \
+        if ((RHO) + 1 < HT) WGD_ISSUE(((RHO) + 1 < HT ? (RHO) + 1 : 0));                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
         bf16x8 bfr[3];                                                                                   \
-        _Pragma("unroll") for (int tx = 0; tx < 3; ++tx) bfr[tx] = frag_from(fb[tx][0], fb[tx][1]);      \
+        _Pragma("unroll") for (int tx = 0; tx < 3; ++tx) bfr[tx] = frag_from(fb[(RHO) & 1][tx][0], fb[(RHO) & 1][tx][1]); \
         _Pragma("unroll") for (int ty = 0; ty < 3; ++ty) {                                               \
             const int r = (RHO) - ty; /* tile row whose g meets x row rho at tap row ty */               \
             if (r >= 0 && r < TH) {                                                                      \
                 _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                          \
-                    const bf16x8 af = frag_from(fa[r % 3][m][0], fa[r % 3][m][1]);                       \
+                    const bf16x8 af = frag_from(fa[r & 3][m][0], fa[r & 3][m][1]);                       \
                     _Pragma("unroll") for (int tx = 0; tx < 3; ++tx)                                     \
                         acc[ty][tx][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[tx], acc[ty][tx][m], 0, 0, 0); \
                     if (ty == 0) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[m], 0, 0, 0); /* every wave: no branch */ \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        if ((RHO) + 1 < HT) WGD_ISSUE(((RHO) + 1 < HT ? (RHO) + 1 : 0));                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
         WGD_ISSUE(0);
