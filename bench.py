@@ -254,6 +254,7 @@ def main():
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.steps):
@@ -265,6 +266,12 @@ def main():
     per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     progress("per-step GPU ms: " + " ".join("%.1f" % v for v in per_step))
     progress("host enqueue time %.1f ms/step" % (host_dt / args.steps * 1e3))
+    ms1 = torch.cuda.memory_stats(device)
+    progress("allocator during the timed region: %d device mallocs, %d frees, %d retries; reserved %.2f GiB" % (
+        ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+        ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+        ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+        ms1.get("reserved_bytes.all.current", 0) / 2 ** 30))
     ms = (ctypes.c_float * cap)()
     n_rec = ctypes.c_int32(0)
     _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))

@@ -285,7 +285,9 @@ class _UNet(torch.autograd.Function):
         ctx.saved_enc = saved
         ctx.saved_dec = dsaved
         ctx.P = P
-        ctx.mask = mask
+        # an alias, not the output object itself: output -> grad_fn -> ctx -> output would be a reference
+        # cycle, and the ~4.5 GB of activations hanging off ctx would live until the cyclic GC runs
+        ctx.mask = mask.detach()
         ctx.scale = dropout_scale(p_drop)
         ctx.n_params = len(params)
         return mask
