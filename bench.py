@@ -225,9 +225,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # Untimed settling before the warm-up proper: the first GPU process on a fresh box sees 100 ms
-    # stalls for its first ~20 steps (driver / page-in; gone in any later process).  Run until five
-    # consecutive steps are within 10 % of the fastest step seen, at most `--settle` steps.
+    # Untimed settling before the warm-up proper (a guard against start-up transients: allocator growth,
+    # code-object loading): run until five consecutive steps are within 10 % of the fastest step seen,
+    # at most `--settle` steps.
     if args.settle > 0:
         progress("settling (untimed, at most %d steps)" % args.settle)
         best, streak = float("inf"), 0
