@@ -118,10 +118,12 @@ def conv_stack_rate(model, raw, params, device, reps=3):
         f_ms.append(ev[0].elapsed_time(ev[1]))
         b_ms.append(ev[1].elapsed_time(ev[2]))
     f, b = min(f_ms[1:]), min(b_ms[1:])
-    tf = 3 * UNET_GFLOP_FWD_PER_SAMPLE * B / (f + b)          # GFLOP / ms = TFLOP/s
+    h, w = batch["loc_data"]["fft_data"].shape[1:3]
+    gf = UNET_GFLOP_FWD_PER_SAMPLE * (h * w) / (640.0 * 640.0)   # conv FLOPs scale with the pixel count
+    tf = 3 * gf * B / (f + b)                                  # GFLOP / ms = TFLOP/s
     return {"bound": "mfma", "unet_fwd_ms": f, "unet_bwd_ms": b, "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
-            "flop": "3 x 28.85 GFLOP/sample (fwd + data grad + weight grad), B=%d" % B,
+            "flop": "3 x %.2f GFLOP/sample (fwd + data grad + weight grad), B=%d" % (gf, B),
             "note": "layers with <= 16 channels at 640x640 are HBM-bound (arithmetic intensity ~70 FLOP/B)"}
 
 
@@ -163,6 +165,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic batches kept resident in HBM")
     ap.add_argument("--nn", choices=["brute", "grid"], default=None,
                     help="nearest-neighbour engine of the dICP (default: the dICP config, 'brute' = north_star's kernel)")
+    ap.add_argument("--network-input", choices=["cartesian", "polar"], default="cartesian",
+                    help="'polar' = the reference's network_input_type='polar' option (U-Net on the 400x3360 polar image, "
+                         "SURVEY 8f.3): a side measurement, not the headline configuration")
     ap.add_argument("--settle", type=int, default=40, help="untimed settling steps before the warm-up (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -198,6 +203,11 @@ def main():
     params = trn.default_params(device)
     params.update({"icp_type": "pt2pl", "icp_loss_fn": {"name": "huber", "metric": 1.0}, "icp_dim": DIM,
                    "max_iter": ICP_ITERS, "dropout": 0.05})
+    polar = args.network_input == "polar"
+    if polar:
+        # a (400,3360) mask cannot be compared with the 640x640 map-point image: that loss is off, as it
+        # has to be upstream (train_icp_weights.py:223-226 would raise on the shape mismatch)
+        params.update({"network_input_type": "polar", "network_output_type": "polar", "loss_map_pts_mask_weight": 0.0})
     lw = trn.loss_weights_from(params)
     torch.manual_seed(1234)
     model = LearnICPWeightPolicy(params).to(device)
@@ -297,10 +307,12 @@ def main():
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: train_icp_weights step fwd+bwd, batch=%d per GPU, 10 dICP "
-                                   "iters, point-to-plane Huber, dim=2; 400x3360 polar radar -> GO-CFAR + peaks + "
-                                   "polar->Cartesian 640x640 -> U-Net (hand-written NHWC bf16 MFMA kernels, fp32 masters) -> dICP (fp32 points, "
-                                   "fp64 normal equations) -> rot+trans+mask_pts loss -> Adam" % B,
+            "config": {"workload": ("BASELINE configs[2]: train_icp_weights step fwd+bwd, batch=%d per GPU, 10 dICP "
+                                    "iters, point-to-plane Huber, dim=2; 400x3360 polar radar -> GO-CFAR + peaks + "
+                                    "polar->Cartesian 640x640 -> U-Net (hand-written NHWC bf16 MFMA kernels, fp32 masters) -> dICP (fp32 points, "
+                                    "fp64 normal equations) -> rot+trans+mask_pts loss -> Adam" % B) if not polar else
+                                   ("NOT the headline configuration: network_input_type='polar' variant of configs[2] (U-Net on the "
+                                    "400x3360 polar image, 3.3x the pixels; rot+trans loss), batch=%d per GPU" % B),
                        "batch_per_gpu": B, "global_batch": B * world, "scan_pts_pad": N_PAD, "map_pts": M_VALID,
                        "map_pts_pad": M_PAD, "icp_iters": ICP_ITERS, "parallelism": "dp%d" % world,
                        "final_loss": float(loss)},

@@ -152,14 +152,19 @@ int mmk_polar_to_cart(const float *polar, const float *azimuths /*B,A*/,
                       void *stream);
 
 /* weights[b,n] = bilinear(mask[b], point n) with zero padding; fake points
- * (x==0 && y==0) get 0.  cart_resolution/W as point_to_cart_idx (radar_utils.py:374-397). */
+ * (x==0 && y==0) get 0.  cart_resolution / cart_pixel_width as point_to_cart_idx
+ * (radar_utils.py:374-397; extract_weights leaves them at 0.2384 / 640): the points are
+ * normalised by the Cartesian grid's width, then F.grid_sample maps [-1,1] onto the mask's own
+ * (H,W) -- so a polar (400,3360) mask is sampled exactly as the reference samples it. */
 int mmk_sample_weights_fwd(const float *mask /*B,H,W*/, const float *pc /*B,N,pc_cols*/,
                            int32_t B, int32_t N, int32_t pc_cols, int32_t H, int32_t W,
-                           float cart_resolution, float *weights /*B,N*/, void *stream);
+                           int32_t cart_pixel_width, float cart_resolution,
+                           float *weights /*B,N*/, void *stream);
 /* grad_mask (B,H,W) is zero-filled here, then receives the scatter-add. */
 int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, int32_t B,
                            int32_t N, int32_t pc_cols, int32_t H, int32_t W,
-                           float cart_resolution, float *grad_mask, void *stream);
+                           int32_t cart_pixel_width, float cart_resolution, float *grad_mask,
+                           void *stream);
 
 int mmk_bev_raster(const float *pc /*B,M,pc_cols*/, int32_t B, int32_t M, int32_t pc_cols,
                    int32_t W, float cart_resolution, float *bev /*B,W,W*/, void *stream);

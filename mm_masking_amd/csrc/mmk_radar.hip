@@ -285,14 +285,16 @@ struct Taps {
     float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ Taps weight_taps(const float *__restrict__ p, int H, int W, float cres)
+// cw = cart_pixel_width of point_to_cart_idx: the normalisation is by the Cartesian grid's width
+// whatever the mask's own shape is (grid_sample then maps [-1,1] onto the mask's H and W).
+__device__ __forceinline__ Taps weight_taps(const float *__restrict__ p, int H, int W, int cw, float cres)
 {
     const float x = p[0], y = p[1];
     const bool fake = (x == 0.0f) && (y == 0.0f);
     const float gu = -x / cres;
     const float gv = y / cres;
-    float gx = gv / (float)(W - 1) * 2.0f;
-    float gy = gu / (float)(W - 1) * 2.0f;
+    float gx = gv / (float)(cw - 1) * 2.0f;
+    float gy = gu / (float)(cw - 1) * 2.0f;
     if (fake) {
         gx = -100.0f;
         gy = -100.0f;
@@ -312,12 +314,12 @@ __device__ __forceinline__ Taps weight_taps(const float *__restrict__ p, int H, 
 }
 
 __global__ void sample_weights_fwd_kernel(const float *__restrict__ mask, const float *__restrict__ pc, int N,
-                                          int cols, int H, int W, float cres, float *__restrict__ out)
+                                          int cols, int H, int W, int cw, float cres, float *__restrict__ out)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= N) return;
-    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cres);
+    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cw, cres);
     const float *m = mask + (size_t)b * H * W;
     auto tap = [&](int yy, int xx) -> float {
         return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? m[(size_t)yy * W + xx] : 0.0f;
@@ -327,12 +329,12 @@ __global__ void sample_weights_fwd_kernel(const float *__restrict__ mask, const 
 }
 
 __global__ void sample_weights_bwd_kernel(const float *__restrict__ gw, const float *__restrict__ pc, int N, int cols,
-                                          int H, int W, float cres, float *__restrict__ gmask)
+                                          int H, int W, int cw, float cres, float *__restrict__ gmask)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= N) return;
-    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cres);
+    const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cw, cres);
     const float g = gw[(size_t)b * N + n];
     float *m = gmask + (size_t)b * H * W;
     auto put = [&](int yy, int xx, float w) {
@@ -465,25 +467,29 @@ extern "C" int mmk_polar_to_cart(const float *polar, const float *azimuths, cons
 }
 
 extern "C" int mmk_sample_weights_fwd(const float *mask, const float *pc, int32_t B, int32_t N, int32_t pc_cols,
-                                      int32_t H, int32_t W, float cart_resolution, float *weights, void *stream)
+                                      int32_t H, int32_t W, int32_t cart_pixel_width, float cart_resolution,
+                                      float *weights, void *stream)
 {
     MMK_REQUIRE(mask && pc && weights, "mmk_sample_weights_fwd: NULL pointer");
-    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2, "mmk_sample_weights_fwd: bad shape");
+    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2 && cart_pixel_width >= 2,
+                "mmk_sample_weights_fwd: bad shape");
     hipLaunchKernelGGL(sample_weights_fwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, mask, pc, N,
-                       pc_cols, H, W, cart_resolution, weights);
+                       pc_cols, H, W, cart_pixel_width, cart_resolution, weights);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
 
 extern "C" int mmk_sample_weights_bwd(const float *grad_weights, const float *pc, int32_t B, int32_t N, int32_t pc_cols,
-                                      int32_t H, int32_t W, float cart_resolution, float *grad_mask, void *stream)
+                                      int32_t H, int32_t W, int32_t cart_pixel_width, float cart_resolution,
+                                      float *grad_mask, void *stream)
 {
     MMK_REQUIRE(grad_weights && pc && grad_mask, "mmk_sample_weights_bwd: NULL pointer");
-    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2, "mmk_sample_weights_bwd: bad shape");
+    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2 && cart_pixel_width >= 2,
+                "mmk_sample_weights_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     MMK_CHECK_HIP(hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * H * W, st));
     hipLaunchKernelGGL(sample_weights_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, grad_weights, pc, N, pc_cols,
-                       H, W, cart_resolution, grad_mask);
+                       H, W, cart_pixel_width, cart_resolution, grad_mask);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -1944,7 +1944,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
 
 // ------------------------------------------------------------------------------------------
 // 2x2 / stride 2 max pooling (nn.MaxPool2d(2,2), icp_weight_policy.py:122-123), NHWC bf16,
-// one thread per (output pixel, 8-channel granule).
+// one thread per (output pixel, 8-channel granule).  Output (H/2, W/2) rounded down, as torch does
+// (the polar 400 x 3360 network input reaches odd sizes: 25 x 105 at the fifth level).
 __global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, int W, int C, bf16 *__restrict__ y)
 {
     const int Ho = H / 2, Wo = W / 2, G = C / 8;
@@ -1998,6 +1999,18 @@ __global__ void maxpool2_bwd_kernel(const bf16 *__restrict__ d, const bf16 *__re
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x8 *>(gz + base + offs[k]) = o[k];
+    // odd H / W (floor pooling): the last row / column belongs to no window and gets a zero gradient
+    const bf16x8 z8 = {};
+    const bool xr = (W & 1) && xo == Wo - 1, yr = (H & 1) && yo == Ho - 1;
+    if (xr) {
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)C) = z8;
+        *reinterpret_cast<bf16x8 *>(gz + base + (size_t)W * C + 2 * (size_t)C) = z8;
+    }
+    if (yr) {
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C) = z8;
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C + C) = z8;
+        if (xr) *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C + 2 * (size_t)C) = z8;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2352,7 +2365,7 @@ extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, 
 
 extern "C" int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *stream)
 {
-    MMK_REQUIRE(x && y && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "mmk_maxpool2_fwd: bad argument");
+    MMK_REQUIRE(x && y && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_fwd: bad argument");
     const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, H, W, C,
                        (bf16 *)y);
@@ -2363,7 +2376,7 @@ extern "C" int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, 
 extern "C" int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
                                 void *gz, void *stream)
 {
-    MMK_REQUIRE(d && gy && gz && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "mmk_maxpool2_bwd: bad argument");
+    MMK_REQUIRE(d && gy && gz && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_bwd: bad argument");
     const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)d,
                        (const bf16 *)gy, B, H, W, C, scale, (bf16 *)gz);

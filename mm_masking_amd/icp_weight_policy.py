@@ -2,8 +2,10 @@
 ``mm_masking/icp_weight_policy.py`` (same constructor ``params`` keys, same
 ``forward``/``icp`` signatures and return values, same ``state_dict`` keys), with
 
-  * the mask U-Net's convolutions on PyTorch-ROCm (MIOpen, bf16 autocast +
-    channels-last by default) — the only MFMA consumer of the path,
+  * the mask U-Net in hand-written NHWC bf16 MFMA kernels (unet_hip.py ->
+    csrc/mmk_unet.hip) for the reference's default configuration (ReLU, no batch
+    norm; Cartesian or polar input of any size >= 32 x 32); the leaky-ReLU /
+    batch-norm variants run the same ``nn.Module`` tree on PyTorch-ROCm (MIOpen),
   * ``extract_weights`` and the differentiable ICP in hand-written HIP kernels
     (radar_utils.py / dICP/ICP.py of this package -> libmmk_hip.so).
 
@@ -168,8 +170,10 @@ class LearnICPWeightPolicy(nn.Module):
 
         if override_mask is None:
             net_in = self._network_input(fft_data, fft_cfar)
+            # any image of at least 32 x 32 (five floor-rounding poolings leave >= 1 pixel): the Cartesian
+            # 640 x 640 grid and the polar 400 x 3360 one (network_input_type "polar") alike
             use_hip = (self.unet_backend == "hip" and net_in.is_cuda and not self.leaky and not self.batch_norm
-                       and net_in.shape[1] <= 4 and net_in.shape[2] % 32 == 0 and net_in.shape[3] % 32 == 0)
+                       and net_in.shape[1] <= 4 and net_in.shape[2] >= 32 and net_in.shape[3] >= 32)
             if use_hip:
                 from . import unet_hip
                 self._step += 1

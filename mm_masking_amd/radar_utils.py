@@ -230,16 +230,17 @@ class _SampleWeights(torch.autograd.Function):
     radar_utils.py:126)."""
 
     @staticmethod
-    def forward(ctx, mask, pc, cart_resolution):
+    def forward(ctx, mask, pc, cart_resolution, cart_pixel_width=640):
         B, H, W = mask.shape
         N, cols = pc.shape[1], pc.shape[2]
         out = torch.empty(B, N, dtype=torch.float32, device=mask.device)
         _lib.check(_lib.lib().mmk_sample_weights_fwd(_lib.ptr(mask, torch.float32, "mask"), _lib.ptr(pc), B, N, cols,
-                                                     H, W, float(cart_resolution), _lib.ptr(out),
+                                                     H, W, int(cart_pixel_width), float(cart_resolution), _lib.ptr(out),
                                                      _lib.stream_ptr(mask.device)))
         ctx.save_for_backward(pc)
         ctx.shape = (B, H, W)
         ctx.cres = float(cart_resolution)
+        ctx.cw = int(cart_pixel_width)
         return out
 
     @staticmethod
@@ -249,8 +250,8 @@ class _SampleWeights(torch.autograd.Function):
         gw = gw.contiguous().float()
         gmask = torch.empty(B, H, W, dtype=torch.float32, device=gw.device)
         _lib.check(_lib.lib().mmk_sample_weights_bwd(_lib.ptr(gw), _lib.ptr(pc), B, pc.shape[1], pc.shape[2], H, W,
-                                                     ctx.cres, _lib.ptr(gmask), _lib.stream_ptr(gw.device)))
-        return gmask, None, None
+                                                     ctx.cw, ctx.cres, _lib.ptr(gmask), _lib.stream_ptr(gw.device)))
+        return gmask, None, None, None
 
 
 def extract_weights(mask, scan_pc):
@@ -261,7 +262,8 @@ def extract_weights(mask, scan_pc):
     m = mask if (mask.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous()) else \
         mask.to(device=dev, dtype=torch.float32).contiguous()
     pc = _lib.dev_f32(scan_pc, dev)
-    weights = _SampleWeights.apply(m, pc, 0.2384)
+    # point_to_cart_idx's defaults (0.2384 m, 640 px) whatever the mask's shape: radar_utils.py:112
+    weights = _SampleWeights.apply(m, pc, 0.2384, 640)
     fake = (pc[:, :, 0] == 0.0) & (pc[:, :, 1] == 0.0)
     real = ~fake
     wd = weights.detach()

@@ -51,16 +51,19 @@ def loss_weights_from(params):
 def prepare_batch(raw, params, max_loc_pts=5120, polar_res=0.0596):
     """GPU counterpart of ICPWeightDataset.__getitem__ (icp_weight_dataset.py:323-362)
     for synthetic input: GO-CFAR -> blob centres -> zero-padded scan cloud, and
-    polar -> Cartesian for the FFT and CFAR images.  ``raw`` holds device tensors
+    polar -> Cartesian for the FFT and CFAR images (kept polar for a polar network).  ``raw`` holds device tensors
     fft_polar (B,400,3360), azimuths (B,400), az_times (B,400), map_pc (B,M,6),
     T_init, T_gt.  Returns the reference's dict-of-dicts batch."""
     fft = raw["fft_polar"]
     az = raw["azimuths"]
     cfar = ru.cfar_mask(fft, polar_res, a_thresh=params["a_thresh"], b_thresh=params["b_thresh"], diff=False)
     pc, _ = ru.extract_pc_padded(cfar, polar_res, az, raw["az_times"], max_loc_pts, diff=False)
-    fft_cart = ru.radar_polar_to_cartesian_diff(fft, az, polar_res)
-    cfar_cart = ru.radar_polar_to_cartesian_diff(cfar, az, polar_res)
-    loc_data = {"raw_pc": pc, "filtered_pc": pc, "fft_data": fft_cart, "fft_cfar": cfar_cart, "timestamp": 0}
+    if params.get("network_input_type", "cartesian") == "cartesian":    # icp_weight_dataset.py:350-352
+        fft_img = ru.radar_polar_to_cartesian_diff(fft, az, polar_res)
+        cfar_img = ru.radar_polar_to_cartesian_diff(cfar, az, polar_res)
+    else:                                                               # polar network: images stay (400,3360)
+        fft_img, cfar_img = fft, cfar
+    loc_data = {"raw_pc": pc, "filtered_pc": pc, "fft_data": fft_img, "fft_cfar": cfar_img, "timestamp": 0}
     map_data = {"pc": raw["map_pc"], "timestamp": 0}
     T_data = {"T_ml_init": raw["T_init"], "T_ml_gt": raw["T_gt"]}
     return {"loc_data": loc_data, "map_data": map_data, "transforms": T_data}

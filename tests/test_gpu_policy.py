@@ -222,13 +222,61 @@ def test_hip_unet_with_cfar_and_range_inputs():
     assert torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item() > 0.9
 
 
-def test_polar_network_input_runs_on_module_path():
-    """network_input_type='polar' (icp_weight_policy.py:61-62): 400x3360-like odd pooling sizes are
-    outside the hand-written kernels' shape contract and run the nn.Module path."""
-    p = _params(network_input_type="polar", network_output_type="polar")
-    torch.manual_seed(2)
-    m = LearnICPWeightPolicy(p).to(DEV)
-    assert tuple(m.range_mask.shape) == (400, 3360)
-    x = torch.rand(1, 100, 168)
-    out = m({"fft_data": x, "fft_cfar": x, "raw_pc": torch.zeros(1, 4, 3)}, {"pc": torch.zeros(1, 4, 6)}, None, mask_only=True)
-    assert out.shape == (1, 100, 168) and torch.isfinite(out).all()
+@pytest.mark.parametrize("tag", ["p", "q"])
+def test_polar_network_golden(golden_dir, tag):
+    """network_input_type='polar' (icp_weight_policy.py:61-62) on the hand-written kernels: non-square
+    input whose sizes go odd under the floor-rounding poolings (50 x 84 -> 25 x 42 -> 12 x 21 -> 6 x 10 ->
+    3 x 5 -> 1 x 2), against the reference module's mask (tests/golden/make_golden_polar.py)."""
+    g = np.load(os.path.join(golden_dir, "polar_net.npz"), allow_pickle=False)
+    over = {"network_input_type": "polar", "network_output_type": "polar", "range_input": tag == "q"}
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(_params(**over)).to(DEV)
+    assert model.unet_backend == "hip" and tuple(model.range_mask.shape) == (400, 3360)
+    model.train()
+    if tag == "q":
+        np.testing.assert_allclose(model.range_mask[:50, :84].cpu().numpy(), g["range_q"], rtol=1e-6)
+        model.range_mask = model.range_mask[:50, :84].contiguous()
+    x = torch.from_numpy(g["x_" + tag])
+    scan = {"fft_data": x, "fft_cfar": torch.zeros_like(x), "raw_pc": torch.zeros(2, 4, 3)}
+    from mm_masking_amd import unet_hip
+    unet_hip.DEBUG = {}
+    try:
+        m = model(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+        assert "fwd" in unet_hip.DEBUG          # the hand-written path ran, not the nn.Module one
+        assert [tuple(t.shape[1:3]) for t in unet_hip.DEBUG["fwd"]["t"]] == [(50, 84), (25, 42), (12, 21), (6, 10), (3, 5), (1, 2)]
+    finally:
+        unet_hip.DEBUG = None
+    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_" + tag], atol=3e-3)
+    (m * torch.from_numpy(g["gsel_" + tag]).to(DEV)).sum().backward()
+    names = [str(n) for n in g["names_" + tag]]
+    grads = dict(model.named_parameters())
+    ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
+    assert np.all(np.isfinite(ga)) and np.abs(ga / g["gabs_" + tag] - 1).max() < 0.6   # bf16 storage: see test_gpu_unet_kernels
+
+
+def test_polar_network_train_step():
+    """A training step on the full-size polar image (400 x 3360 -> ... -> 12 x 105) end to end: the mask is
+    sampled with Cartesian point indices exactly as the reference does (radar_utils.py:108-126 — its latent
+    bug, kept), the ICP and the loss back-propagate into every parameter through the hand-written kernels."""
+    raw, params, batch = _small_batch()
+    params = dict(params, network_input_type="polar", network_output_type="polar", dropout=0.05)
+    torch.manual_seed(3)
+    model = LearnICPWeightPolicy(params).to(DEV)
+    model.train()
+    loc = dict(batch["loc_data"])
+    loc["fft_data"] = raw["fft_polar"]
+    loc["fft_cfar"] = torch.zeros_like(raw["fft_polar"])
+    from mm_masking_amd import unet_hip
+    unet_hip.DEBUG = {}
+    try:
+        T_est, mask, n_non0 = model(loc, batch["map_data"], raw["T_init"])
+        sizes = [tuple(t.shape[1:3]) for t in unet_hip.DEBUG["fwd"]["t"]]
+    finally:
+        unet_hip.DEBUG = None
+    assert sizes == [(400, 3360), (200, 1680), (100, 840), (50, 420), (25, 210), (12, 105)]
+    assert mask.shape == (2, 400, 3360) and T_est.shape == (2, 4, 4)
+    loss = T_est[:, :2, 3].norm(dim=1).mean() + T_est[:, 1, 0].abs().mean()
+    loss.backward()
+    for n, q in model.named_parameters():
+        assert q.grad is not None and torch.isfinite(q.grad).all(), n
+    assert sum(q.grad.abs().sum().item() for q in model.parameters()) > 0

@@ -145,6 +145,25 @@ def test_extract_weights_golden(golden_dir):
     np.testing.assert_allclose(wk[0], [1.0, 0.0, 0.0], atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["s", "f"])
+def test_extract_weights_non_square_mask(golden_dir, tag):
+    """Masks that are not the 640 x 640 Cartesian grid — (40,96) and the polar (400,3360): points are
+    normalised by the 640-pixel width, grid_sample stretches [-1,1] over the mask (radar_utils.py:112,126)."""
+    g = _load(golden_dir, "polar_net.npz")
+    B, H, W = (int(v) for v in g["ew_shape_" + tag])
+    mask = np.random.default_rng(int(g["ew_seed_" + tag])).uniform(0, 1, size=(B, H, W)).astype(np.float32)
+    mt = _g(mask).requires_grad_(True)
+    w, dmn, mn, mean_w, max_w, min_w = ru.extract_weights(mt, _g(g["ew_pts_" + tag]))
+    np.testing.assert_allclose(w.detach().cpu().numpy(), g["ew_w_" + tag], atol=2e-5)
+    np.testing.assert_allclose([dmn.item(), mn.item(), mean_w.item(), max_w.item(), min_w.item()], g["ew_stats_" + tag],
+                               rtol=1e-5, atol=2e-5)
+    (w * _g(g["ew_gw_" + tag])).sum().backward()
+    want = np.zeros_like(mask)
+    i = g["ew_gidx_" + tag]
+    want[i[0], i[1], i[2]] = g["ew_gval_" + tag]
+    np.testing.assert_allclose(mt.grad.cpu().numpy(), want, atol=3e-5)
+
+
 def test_bev_golden_and_point_idx(golden_dir):
     g = _load(golden_dir, "radar_points.npz")
     bev = ru.extract_bev_from_pts(_g(g["bev_pts"])).cpu().numpy()

@@ -282,6 +282,19 @@ def test_aux_kernels_vs_torch():
     gz = uh.maxpool2_bwd(dn, _nhwc(gy), 1.25)
     want = (dref.grad * (dref > 0) * 1.25).permute(0, 2, 3, 1)
     assert (gz.float() - want).abs().max().item() < 0.02
+    # odd sizes: floor-rounded output, the last row / column gets a zero gradient
+    for (hh, ww) in [(13, 20), (12, 21), (25, 105), (3, 5)]:
+        d = F.relu(torch.randn(2, 16, hh, ww, generator=g)).to(DEV)
+        dn = _nhwc(d)
+        p = uh.maxpool2(dn)
+        dref = dn.float().permute(0, 3, 1, 2).requires_grad_(True)
+        pref = F.max_pool2d(dref, 2, 2)
+        assert p.shape == (2, hh // 2, ww // 2, 16) and torch.equal(p.float(), pref.permute(0, 2, 3, 1))
+        gy = torch.randn(2, 16, hh // 2, ww // 2, generator=g).to(DEV)
+        pref.backward(gy.to(torch.bfloat16).float())
+        gz = uh.maxpool2_bwd(dn, _nhwc(gy), 1.25)
+        want = (dref.grad * (dref > 0) * 1.25).permute(0, 2, 3, 1)
+        assert (gz.float() - want).abs().max().item() < 0.02
     # bilinear upsample (align_corners) fwd / bwd
     for (hs, ws, ho, wo, ch) in [(20, 20, 40, 40, 8), (5, 7, 10, 14, 8), (40, 40, 80, 80, 8), (6, 6, 13, 11, 8), (3, 4, 30, 44, 8),
                                  (20, 24, 40, 48, 16), (12, 20, 24, 40, 32), (9, 10, 18, 20, 64), (5, 5, 10, 10, 128)]:
@@ -392,10 +405,12 @@ def _unet_on_hip_activations(model, x, fwd, drop=0.0):
     return torch.sigmoid(F.conv2d(cur, fl.weight.to(torch.bfloat16).float(), fl.bias)).squeeze(1)
 
 
-@pytest.mark.parametrize("B,H,W,drop", [(2, 64, 64, 0.0), (2, 160, 160, 0.0), (2, 96, 96, 0.1), (3, 64, 160, 0.05), (1, 320, 96, 0.0)])
+@pytest.mark.parametrize("B,H,W,drop", [(2, 64, 64, 0.0), (2, 160, 160, 0.0), (2, 96, 96, 0.1), (3, 64, 160, 0.05), (1, 320, 96, 0.0),
+                                        (2, 50, 84, 0.0), (1, 100, 210, 0.05), (1, 200, 420, 0.0)])
 def test_unet_hip_backward_exact_on_pinned_activations(B, H, W, drop):
     """Whole network, forward + all 46 parameter gradients, against autograd on the activations the HIP
-    path produced (square and non-square images, batch sizes that are not multiples of the XCD count)."""
+    path produced (square and non-square images, batch sizes that are not multiples of the XCD count, sizes
+    that go odd under the floor-rounding poolings as the polar 400 x 3360 input does)."""
     model = _policy(drop, torch.float32)
     model.train()
     g = torch.Generator().manual_seed(1)

@@ -187,3 +187,46 @@ def test_losses(golden_dir):
         np.testing.assert_allclose(got, g["comp_" + tag], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(Tpt.grad.numpy(), g["gT_" + tag], atol=1e-6)
         assert abs(mt.grad.double().abs().sum().item() - float(g["gmask_abs_" + tag])) < 1e-4 * float(g["gmask_abs_" + tag])
+
+
+# ----------------------------------------------------------------------------- polar-domain network
+@pytest.mark.parametrize("tag", ["p", "q"])
+def test_unet_polar_sizes(golden_dir, tag):
+    """network_input_type='polar': non-square input whose sizes go odd under the poolings
+    (50 x 84 -> ... -> 1 x 2); fixtures from tests/golden/make_golden_polar.py."""
+    g = _load(golden_dir, "polar_net.npz")
+    in_ch = 1 if tag == "p" else 2
+    sd = unet_ref.init_state_dict(in_ch, 1234)
+    names = [str(n) for n in g["names_" + tag]]
+    assert names == list(sd.keys())
+    for v in sd.values():
+        v.requires_grad_(True)
+    fft = torch.from_numpy(g["x_" + tag])
+    rng_mask = torch.from_numpy(g["range_q"]) if tag == "q" else None
+    m = unet_ref.unet_mask(unet_ref.assemble_input(fft, None, rng_mask), sd)
+    np.testing.assert_allclose(m.detach().numpy(), g["mask_" + tag], atol=2e-6)
+    (m * torch.from_numpy(g["gsel_" + tag])).sum().backward()
+    gs = np.array([sd[k].grad.double().sum().item() for k in names])
+    ga = np.array([sd[k].grad.double().abs().sum().item() for k in names])
+    np.testing.assert_allclose(ga, g["gabs_" + tag], rtol=2e-3, atol=1e-6)
+    assert np.all(np.abs(gs - g["gsum_" + tag]) <= 2e-3 * np.maximum(g["gabs_" + tag], 1e-3))
+    if tag == "q":      # R7: the polar range grid the reference stacks as a channel
+        np.testing.assert_allclose(R.form_polar_range_grid(0.0596)[:50, :84], g["range_q"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["s", "f"])
+def test_extract_weights_non_square_mask(golden_dir, tag):
+    """The reference normalises points by the 640-pixel Cartesian width and lets grid_sample stretch
+    [-1,1] over whatever mask it is given: (40,96) and the polar (400,3360)."""
+    g = _load(golden_dir, "polar_net.npz")
+    B, H, W = (int(v) for v in g["ew_shape_" + tag])
+    mask = np.random.default_rng(int(g["ew_seed_" + tag])).uniform(0, 1, size=(B, H, W)).astype(np.float32)
+    pts = g["ew_pts_" + tag]
+    w, dmn, mn, mean_w, max_w, min_w = R.extract_weights(mask, pts)
+    np.testing.assert_allclose(w, g["ew_w_" + tag], atol=2e-5)
+    np.testing.assert_allclose([dmn, mn, mean_w, max_w, min_w], g["ew_stats_" + tag], rtol=1e-5, atol=2e-5)
+    gm = R.extract_weights_grad_mask(mask.shape, pts, g["ew_gw_" + tag])
+    want = np.zeros_like(mask)
+    i = g["ew_gidx_" + tag]
+    want[i[0], i[1], i[2]] = g["ew_gval_" + tag]
+    np.testing.assert_allclose(gm, want, atol=3e-5)
