@@ -7,6 +7,7 @@ reference driver ``mm_masking/train_icp_weights.py``:
   eval_validation_loss    :255-273
   generate_baseline       :275-344   override-mask baselines (U-Net bypassed)
   default_params          :354-410   the hard-coded ``params`` dict
+  fit                     :486-596   the epoch loop (best_policy.pt / epoch_N.pt), plus resume
 
 Neptune logging, figures and checkpoint upload (observability SaaS) are out of
 scope.  What the reference's Dataset/DataLoader does per item on the CPU
@@ -37,7 +38,7 @@ def default_params(device=None):
         "loss_cfar_mask_weight": 0.0, "num_pts_weight": 0.0, "optimizer": "adam", "icp_loss_only_iter": -1,
         "max_iter": 10, "network_input_type": "cartesian", "network_output_type": "cartesian",
         "binary_inference": False, "norm_weights": True, "fft_input": True, "cfar_input": False,
-        "range_input": False,
+        "range_input": False, "num_epochs": 30,
     }
 
 
@@ -234,6 +235,88 @@ def make_optimizer(policy, params):
     if params["optimizer"] == "adam":
         return torch.optim.Adam(policy.parameters(), lr=params["learning_rate"])
     return torch.optim.SGD(policy.parameters(), lr=params["learning_rate"], nesterov=True, momentum=1.0)
+
+
+# ----------------------------------------------------------------------------- epoch loop + resume
+def save_checkpoint(path, policy, opt, epoch, best_norm):
+    """Everything a run needs to continue where it stopped (absent upstream, which saves the
+    state_dict only: train_icp_weights.py:534-537,577-578): parameters, optimizer state, the epoch
+    that finished, the best validation norm so far and the policy's dropout-seed counter.  Tensors,
+    numbers and plain containers only, so it loads with ``weights_only=True``."""
+    torch.save({"model": policy.state_dict(), "optimizer": opt.state_dict(), "epoch": int(epoch),
+                "best_norm": float(best_norm), "policy_step": int(getattr(policy, "_step", 0))}, path)
+
+
+def load_checkpoint(path, policy, opt=None, map_location=None):
+    """Restores what ``save_checkpoint`` wrote; a bare state_dict file (the reference's
+    ``best_policy.pt`` / ``epoch_N.pt``) loads the parameters only.  -> (next epoch, best_norm)."""
+    ck = torch.load(path, map_location=map_location, weights_only=True)
+    if "model" not in ck:
+        policy.load_state_dict(ck)
+        return 0, None
+    policy.load_state_dict(ck["model"])
+    if opt is not None:
+        opt.load_state_dict(ck["optimizer"])
+    policy._step = int(ck.get("policy_step", 0))
+    return int(ck["epoch"]) + 1, float(ck["best_norm"])
+
+
+def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_dir, loss_weights=None,
+        start_epoch=0, best_norm=None, grad_sync=None, is_main=True, log=print):
+    """The reference's epoch loop (train_icp_weights.py:486-596) without Neptune: baselines, a
+    validation before training, then per epoch train_policy -> validate_policy, ``best_policy.pt`` when
+    the total validation norm improves (or at epoch 0), ``epoch_N.pt`` every epoch (both bare
+    state_dicts, as upstream), and finally a validation of the best policy.  Additionally writes
+    ``resume.pt`` (save_checkpoint) every epoch; pass ``start_epoch`` / ``best_norm`` from
+    ``load_checkpoint`` to continue a run.  Returns a history dict."""
+    import os
+    dev = params["device"]
+    lw = loss_weights if loss_weights is not None else loss_weights_from(params)
+    if is_main:
+        os.makedirs(checkpoint_dir, exist_ok=True)
+    best_path = os.path.join(checkpoint_dir, "best_policy.pt")
+    hist = {"loss": [], "loss_comp": [], "acc": [], "epoch_train_time": [], "epoch_val_time": []}
+    if start_epoch == 0:
+        hist["train_baseline"] = generate_baseline(policy, training_iterator, baseline_type="train", device=dev, binary=False,
+                                                   loss_weights=lw, gt_eye=params["gt_eye"])
+        hist["val_baseline"] = generate_baseline(policy, validation_iterator, baseline_type="val", device=dev,
+                                                 binary=params["binary_inference"], gt_eye=params["gt_eye"])
+        avg_norm = validate_policy(policy, validation_iterator, device=dev, binary=params["binary_inference"],
+                                   gt_eye=params["gt_eye"], epoch=-1)[0]
+        best_norm = float(avg_norm[0, 0])
+        log("Norm before training: %.6f" % best_norm)
+    for epoch in range(start_epoch, params["num_epochs"]):
+        tic = time.time()
+        mean_loss, mean_loss_comp = train_policy(policy, training_iterator, opt, lw, device=dev, epoch=epoch,
+                                                 icp_loss_only_iter=params["icp_loss_only_iter"], gt_eye=params["gt_eye"],
+                                                 grad_sync=grad_sync)
+        mean_loss = float(mean_loss)
+        t_train = time.time() - tic
+        tic = time.time()
+        avg_norm = validate_policy(policy, validation_iterator, epoch=epoch, device=dev, binary=params["binary_inference"],
+                                   gt_eye=params["gt_eye"])[0]
+        t_val = time.time() - tic
+        total = float(avg_norm[0, 0])
+        if total < best_norm or epoch == 0:
+            best_norm = total
+            if is_main:
+                torch.save(policy.state_dict(), best_path)
+        if is_main:
+            torch.save(policy.state_dict(), os.path.join(checkpoint_dir, "epoch_{}.pt".format(epoch)))
+            save_checkpoint(os.path.join(checkpoint_dir, "resume.pt"), policy, opt, epoch, best_norm)
+        hist["loss"].append(mean_loss)
+        hist["loss_comp"].append({k: float(v) for k, v in mean_loss_comp.items()})
+        hist["acc"].append([float(v) for v in avg_norm[0]])
+        hist["epoch_train_time"].append(t_train)
+        hist["epoch_val_time"].append(t_val)
+        log("EPOCH %d  loss %.5f  norm %.5f  best %.5f  (train %.1f s, val %.1f s)" % (epoch, mean_loss, total, best_norm,
+                                                                                      t_train, t_val))
+    hist["best_norm"] = best_norm
+    if is_main and os.path.exists(best_path):
+        policy.load_state_dict(torch.load(best_path, map_location=dev, weights_only=True))
+        hist["final_acc"] = [float(v) for v in validate_policy(policy, validation_iterator, device=dev,
+                                                              binary=params["binary_inference"], gt_eye=params["gt_eye"])[0][0]]
+    return hist
 
 
 class SyntheticIterator:
