@@ -2024,55 +2024,134 @@ __device__ __forceinline__ void up_coord(int o, float r, int n_src, int &i0, int
     l0 = 1.0f - l1;
 }
 
-__global__ void upsample_fwd_kernel(const bf16 *__restrict__ x, int B, int Hs, int Ws, int C, int Ho, int Wo,
-                                    bf16 *__restrict__ y)
+// (element index -> (pixel, 8-channel granule): a shift when the granule count is a power of two)
+template <bool POW2>
+__device__ __forceinline__ void split_granule(int e, int G, int lg, int &pix, int &gc)
 {
-    // grid: x = (output pixel, granule) of one output row, y = output row, z = image
-    const int G = C / 8;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Wo * G) return;
-    const int gc = e % G, xo = e / G;
-    const int yo = blockIdx.y, b = blockIdx.z;
-    const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
-    const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    up_coord(yo, rh, Hs, y0, y1, ly0, ly1);
-    up_coord(xo, rw, Ws, x0, x1, lx0, lx1);
-    const bf16 *base = x + (size_t)b * Hs * Ws * C + gc * 8;
-    const bf16x8 a00 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y0 * Ws + x0) * C);
-    const bf16x8 a01 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y0 * Ws + x1) * C);
-    const bf16x8 a10 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y1 * Ws + x0) * C);
-    const bf16x8 a11 = *reinterpret_cast<const bf16x8 *>(base + ((size_t)y1 * Ws + x1) * C);
+    if constexpr (POW2) {
+        gc = e & (G - 1);
+        pix = e >> lg;
+    } else {
+        gc = e % G;
+        pix = e / G;
+    }
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(v[j] << 16);
+        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8])
+{
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        o[j] = (bf16)(ly0 * (lx0 * (float)a00[j] + lx1 * (float)a01[j]) + ly1 * (lx0 * (float)a10[j] + lx1 * (float)a11[j]));
-    *reinterpret_cast<bf16x8 *>(y + (((size_t)b * Ho + yo) * Wo + xo) * C + gc * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)f[j];
+    return __builtin_bit_cast(u32x4, o);
+}
+
+// rh / rw = (n_src - 1) / (n_out - 1), worked out once on the host.  A thread owns one (column, granule)
+// of UP_ROWS consecutive output rows: the column taps and weights are formed once, every source row is
+// fetched and interpolated along x once (kept for the next output row, which shares it at factors >= 2),
+// and an output row is one multiply and one fused multiply-add per channel.  Row bases are
+// wave-uniform, per-lane offsets 32-bit.
+constexpr int UP_ROWS = 4;
+
+template <bool POW2>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const bf16 *__restrict__ x, int Hs, int Ws, int C, int Ho, int Wo,
+                                                           float rh, float rw, int lg, bf16 *__restrict__ y)
+{
+    // grid: x = (output pixel, granule) of one output row, y = group of UP_ROWS output rows, z = image
+    const int G = C >> 3;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Wo * G) return;
+    int gc, xo;
+    split_granule<POW2>(e, G, lg, xo, gc);
+    const int b = blockIdx.z;
+    int x0, x1;
+    float lx0, lx1;
+    up_coord(xo, rw, Ws, x0, x1, lx0, lx1);
+    const int o0 = x0 * C + gc * 8, o1 = x1 * C + gc * 8;
+    const bf16 *img = x + (size_t)b * Hs * Ws * C;
+    auto hrow = [&](int ysrc, float (&h)[8]) {
+        const bf16 *r = img + (size_t)ysrc * Ws * C;
+        float a0[8], a1[8];
+        unpack8(*reinterpret_cast<const u32x4 *>(r + o0), a0);
+        unpack8(*reinterpret_cast<const u32x4 *>(r + o1), a1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = __builtin_fmaf(lx1, a1[j], lx0 * a0[j]);
+    };
+    float h0[8], h1[8];
+    int hy0 = -1, hy1 = -1;                // source rows held in h0 / h1 (uniform over the block)
+#pragma unroll
+    for (int r = 0; r < UP_ROWS; ++r) {
+        const int yo = blockIdx.y * UP_ROWS + r;
+        if (yo >= Ho) break;
+        int y0, y1;
+        float ly0, ly1;
+        up_coord(yo, rh, Hs, y0, y1, ly0, ly1);
+        if (y0 != hy0) {
+            if (y0 == hy1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h0[j] = h1[j];
+            } else {
+                hrow(y0, h0);
+            }
+            hy0 = y0;
+        }
+        if (y1 != hy1) {
+            if (y1 == hy0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h1[j] = h0[j];
+            } else {
+                hrow(y1, h1);
+            }
+            hy1 = y1;
+        }
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(ly1, h1[j], ly0 * h0[j]);
+        *reinterpret_cast<u32x4 *>(y + ((size_t)b * Ho + yo) * Wo * C + (size_t)e * 8) = pack8(o);
+    }
 }
 
 // Gather form of the adjoint (deterministic, no atomics): each source pixel sums the output
 // pixels it was interpolated into; optional ReLU/dropout factor of the source activation.
-// The weights along x do not depend on the output row: they are worked out once per thread.
-__global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, int Ws, int C, int Ho, int Wo,
-                                    const bf16 *__restrict__ relu_src, float scale, bf16 *__restrict__ gx)
+// A thread owns one (column, granule) of UP_ROWS consecutive source rows.  The weights along x do not
+// depend on the row: the candidate output columns are scanned once per thread (exactly the forward's
+// up_coord arithmetic) and the run of non-zero weights (at most NW wide for up-sampling factors >= 2) is
+// compacted to the front.  Every output row in reach is then summed along x once (NW unconditional
+// 16-byte loads) and added to the one or two source rows it was interpolated from.  Wider runs
+// (factors < 2) take the generic loop.
+template <bool POW2>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16 *__restrict__ gy, int Hs, int Ws, int C, int Ho, int Wo,
+                                                           float rh, float rw, int lg, const bf16 *__restrict__ relu_src,
+                                                           float scale, bf16 *__restrict__ gx)
 {
-    // grid: x = (source pixel, granule) of one source row, y = source row, z = image
-    constexpr int MAXW = 8;
-    const int G = C / 8;
+    // grid: x = (source pixel, granule) of one source row, y = group of UP_ROWS source rows, z = image
+    constexpr int MAXW = 8, NW = 5, R = UP_ROWS;
+    const int G = C >> 3;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Ws * G) return;
-    const int gc = e % G, xs = e / G;
-    const int ys = blockIdx.y, b = blockIdx.z;
-    const float rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
-    const float rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
-    const int ylo = (rh > 0.f) ? max(0, (int)floorf((float)(ys - 1) / rh) - 1) : 0;
-    const int yhi = (rh > 0.f) ? min(Ho - 1, (int)ceilf((float)(ys + 1) / rh) + 1) : Ho - 1;
+    int gc, xs;
+    split_granule<POW2>(e, G, lg, xs, gc);
+    const int ys0 = blockIdx.y * R, b = blockIdx.z;
+    const int ys1 = min(ys0 + R, Hs) - 1;             // last source row of the group
+    const int ylo = (rh > 0.f) ? max(0, (int)floorf((float)(ys0 - 1) / rh) - 1) : 0;
+    const int yhi = (rh > 0.f) ? min(Ho - 1, (int)ceilf((float)(ys1 + 1) / rh) + 1) : Ho - 1;
     const int xlo = (rw > 0.f) ? max(0, (int)floorf((float)(xs - 1) / rw) - 1) : 0;
     const int xhi = (rw > 0.f) ? min(Wo - 1, (int)ceilf((float)(xs + 1) / rw) + 1) : Wo - 1;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool small = (xhi - xlo + 1) <= MAXW;          // always true for up-sampling factors >= ~1.5
+    float acc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
     float wxs[MAXW];
+    int k0 = MAXW, k1 = -1;
 #pragma unroll
     for (int k = 0; k < MAXW; ++k) {
         const int xo = xlo + k;
@@ -2081,23 +2160,42 @@ __global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, 
         up_coord(xo, rw, Ws, x0, x1, m0, m1);
         const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
         wxs[k] = (xo <= xhi) ? wx : 0.f;
+        if (wxs[k] != 0.f) {
+            k0 = min(k0, k);
+            k1 = k;
+        }
+    }
+    k0 = (k1 < 0) ? 0 : k0;
+    // every lane of the wave must fit the compact form (the loops below are wave-uniform)
+    const bool compact = __all((xhi - xlo + 1) <= MAXW && k0 <= MAXW - NW && k1 - k0 < NW);
+    const bf16 *gimg = gy + (size_t)b * Ho * Wo * C + gc * 8;
+    float wn[NW];
+    int on[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        float w = wxs[i];                       // k0 == 0
+#pragma unroll
+        for (int q = 1; q <= MAXW - NW; ++q) w = (k0 == q) ? wxs[i + q] : w;
+        wn[i] = w;
+        on[i] = min(xlo + k0 + i, Wo - 1) * C;  // (past the run the weight is zero)
     }
     for (int yo = ylo; yo <= yhi; ++yo) {
         int y0, y1;
         float l0, l1;
         up_coord(yo, rh, Hs, y0, y1, l0, l1);
-        const float wy = ((y0 == ys) ? l0 : 0.f) + ((y1 == ys) ? l1 : 0.f);
-        if (wy == 0.f) continue;
-        const bf16 *grow = gy + (((size_t)b * Ho + yo) * Wo) * C + gc * 8;
-        if (small) {
+        if (y1 < ys0 || y0 > ys1) continue;                 // (uniform: the rows are the block's)
+        const bf16 *grow = gimg + (size_t)yo * Wo * C;
+        float hs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the output row summed along x for this column
+        if (compact) {
+            u32x4 v[NW];
 #pragma unroll
-            for (int k = 0; k < MAXW; ++k) {
-                if (wxs[k] != 0.f) {
-                    const bf16x8 g = *reinterpret_cast<const bf16x8 *>(grow + (size_t)(xlo + k) * C);
-                    const float w = wy * wxs[k];
+            for (int i = 0; i < NW; ++i) v[i] = *reinterpret_cast<const u32x4 *>(grow + on[i]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
-                }
+            for (int i = 0; i < NW; ++i) {
+                float g[8];
+                unpack8(v[i], g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hs[j] = __builtin_fmaf(wn[i], g[j], hs[j]);
             }
         } else {
             for (int xo = xlo; xo <= xhi; ++xo) {
@@ -2106,24 +2204,35 @@ __global__ void upsample_bwd_kernel(const bf16 *__restrict__ gy, int B, int Hs, 
                 up_coord(xo, rw, Ws, x0, x1, m0, m1);
                 const float wx = ((x0 == xs) ? m0 : 0.f) + ((x1 == xs) ? m1 : 0.f);
                 if (wx == 0.f) continue;
-                const bf16x8 g = *reinterpret_cast<const bf16x8 *>(grow + (size_t)xo * C);
-                const float w = wy * wx;
+                float g[8];
+                unpack8(*reinterpret_cast<const u32x4 *>(grow + (size_t)xo * C), g);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += w * (float)g[j];
+                for (int j = 0; j < 8; ++j) hs[j] = __builtin_fmaf(wx, g[j], hs[j]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ys = ys0 + r;
+            const float wy = ((y0 == ys) ? l0 : 0.f) + ((y1 == ys) ? l1 : 0.f);
+            if (wy != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(wy, hs[j], acc[r][j]);
             }
         }
     }
-    const size_t ps = ((size_t)b * Hs + ys) * Ws + xs;
-    bf16x8 o;
-    if (relu_src) {
-        const bf16x8 sv = *reinterpret_cast<const bf16x8 *>(relu_src + ps * C + gc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)sv[j] > 0.f) ? acc[j] * scale : 0.f);
-    } else {
+    for (int r = 0; r < R; ++r) {
+        const int ys = ys0 + r;
+        if (ys >= Hs) break;
+        const size_t po = (((size_t)b * Hs + ys) * Ws) * C + (size_t)e * 8;
+        if (relu_src) {
+            float sv[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(relu_src + po), sv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+            for (int j = 0; j < 8; ++j) acc[r][j] = (sv[j] > 0.f) ? acc[r][j] * scale : 0.f;
+        }
+        *reinterpret_cast<u32x4 *>(gx + po) = pack8(acc[r]);
     }
-    *reinterpret_cast<bf16x8 *>(gx + ps * C + gc * 8) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2384,13 +2493,37 @@ extern "C" int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_
     return MMK_OK;
 }
 
+namespace {
+struct UpGeom {
+    float rh, rw;
+    int lg;          // log2 of the granule count, or -1
+};
+UpGeom up_geom(int Hs, int Ws, int C, int Ho, int Wo)
+{
+    UpGeom g;
+    g.rh = (Ho > 1) ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    g.rw = (Wo > 1) ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    const int G = C / 8;
+    g.lg = -1;
+    for (int l = 0; l < 16; ++l)
+        if ((1 << l) == G) g.lg = l;
+    return g;
+}
+}  // namespace
+
 extern "C" int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo, void *y,
                                 void *stream)
 {
     MMK_REQUIRE(x && y && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_fwd: bad argument");
     MMK_REQUIRE(Ho <= 65535 && B <= 65535, "mmk_upsample_fwd: shape exceeds the launch grid");
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(nblk((size_t)Wo * (C / 8), 256), Ho, B), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16 *)x, B, Hs, Ws, C, Ho, Wo, (bf16 *)y);
+    const UpGeom ug = up_geom(Hs, Ws, C, Ho, Wo);
+    const dim3 grid(nblk((size_t)Wo * (C / 8), 256), (Ho + UP_ROWS - 1) / UP_ROWS, B);
+    if (ug.lg >= 0)
+        hipLaunchKernelGGL(upsample_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, Hs, Ws, C, Ho, Wo,
+                           ug.rh, ug.rw, ug.lg, (bf16 *)y);
+    else
+        hipLaunchKernelGGL(upsample_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, Hs, Ws, C, Ho, Wo,
+                           ug.rh, ug.rw, 0, (bf16 *)y);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2400,8 +2533,14 @@ extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t W
 {
     MMK_REQUIRE(gy && gx && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_bwd: bad argument");
     MMK_REQUIRE(Hs <= 65535 && B <= 65535, "mmk_upsample_bwd: shape exceeds the launch grid");
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(nblk((size_t)Ws * (C / 8), 256), Hs, B), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16 *)gy, B, Hs, Ws, C, Ho, Wo, (const bf16 *)relu_src, scale, (bf16 *)gx);
+    const UpGeom ug = up_geom(Hs, Ws, C, Ho, Wo);
+    const dim3 grid(nblk((size_t)Ws * (C / 8), 256), (Hs + UP_ROWS - 1) / UP_ROWS, B);
+    if (ug.lg >= 0)
+        hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
+                           ug.rh, ug.rw, ug.lg, (const bf16 *)relu_src, scale, (bf16 *)gx);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
+                           ug.rh, ug.rw, 0, (const bf16 *)relu_src, scale, (bf16 *)gx);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

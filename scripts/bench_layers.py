@@ -10,6 +10,8 @@ from mm_masking_amd import unet_hip as uh  # noqa: E402
 
 DEV = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
+DEEP_ONLY = len(sys.argv) > 2 and sys.argv[2] == "deep"      # only the >= 64-channel layers, no elementwise kernels
+ELEM_ONLY = len(sys.argv) > 2 and sys.argv[2] == "elem"      # only the elementwise kernels
 H0 = 640
 
 
@@ -46,6 +48,8 @@ def main():
                                                                     "dgrad us", "TF/s", "GB/s", "wgrad us", "TF/s"))
     for name, H, c1, c2, co in layers:
         cin = c1 + c2
+        if ELEM_ONLY or (DEEP_ONLY and max(cin, co) < 64):
+            continue
         x1 = rnd(B, H, H, c1)
         x2 = rnd(B, H, H, c2) if c2 else None
         w = torch.randn(co, cin, 3, 3, device=DEV) / (3 * cin ** 0.5)
@@ -75,6 +79,8 @@ def main():
             t_w, flop / t_w * 1e-6), flush=True)
         del x1, x2, y, g, o1
     print("sum us: fwd %.0f dgrad %.0f wgrad %.0f" % (tot["fwd"], tot["dgrad"], tot["wgrad"]))
+    if DEEP_ONLY:
+        return
     # elementwise layers
     for H, C in [(640, 8), (320, 16), (160, 32), (80, 64), (40, 128)]:
         pass
