@@ -1827,10 +1827,10 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
                                                             const float *__restrict__ bias, int B, int H, int W,
                                                             bf16 *__restrict__ y)
 {
-    __shared__ float ws[8 * 4 * 9 + 8];
-    for (int i = threadIdx.x; i < 8 * CIN * 9; i += blockDim.x) ws[i] = Wt[i];
-    if (threadIdx.x < 8) ws[8 * 4 * 9 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-    __syncthreads();
+    // (weights and bias are read at wave-uniform addresses: scalar loads, operands straight from SGPRs)
+    float bs[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) bs[co] = bias ? bias[co] : 0.f;
     const int Wq = W >> 2;
     const int nq = B * H * Wq;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += gridDim.x * blockDim.x) {
@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
 #pragma unroll
         for (int px = 0; px < 4; ++px)
 #pragma unroll
-            for (int co = 0; co < 8; ++co) acc[px][co] = ws[8 * 4 * 9 + co];
+            for (int co = 0; co < 8; ++co) acc[px][co] = bs[co];
         for (int c = 0; c < CIN; ++c) {
             const float *xc = x + ((size_t)b * CIN + c) * H * W;
 #pragma unroll
@@ -1852,9 +1852,9 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
                 for (int co = 0; co < 8; ++co) {
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) {
-                        const float w = ws[(co * CIN + c) * 9 + dy * 3 + tx];
+                        const float w = Wt[(co * CIN + c) * 9 + dy * 3 + tx];
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) acc[px][co] += v[px + tx] * w;
+                        for (int px = 0; px < 4; ++px) acc[px][co] = __builtin_fmaf(v[px + tx], w, acc[px][co]);
                     }
                 }
             }
@@ -1914,7 +1914,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) acc[co * 9 + dy * 3 + tx] += gf[px][co] * v[dy][px + tx];
+                        for (int px = 0; px < 4; ++px)
+                            acc[co * 9 + dy * 3 + tx] = __builtin_fmaf(gf[px][co], v[dy][px + tx], acc[co * 9 + dy * 3 + tx]);
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[72 + co] += (gf[0][co] + gf[1][co]) + (gf[2][co] + gf[3][co]);
 #pragma unroll
