@@ -1687,7 +1687,18 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
         const int e = e0 + 4 * ln;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (vec && e + 3 < total) {
-            for (int sl = sg; sl < S; sl += 4) {
+            int sl = sg;
+            // eight slices in flight per lane (the sums stay in slice order)
+            for (; sl + 28 < S; sl += 32) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4 *>(src + (size_t)(sl + 4 * u) * total + e);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w;
+                }
+            }
+            for (; sl < S; sl += 4) {
                 const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)sl * total + e);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
