@@ -166,6 +166,14 @@ int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, i
                            int32_t cart_pixel_width, float cart_resolution, float *grad_mask,
                            void *stream);
 
+/* Statistics extract_weights returns next to the weights (radar_utils.py:130-138) and the policy's
+ * mean_all_pts (icp_weight_policy.py:209-212), over the real points (not x==0 && y==0):
+ * out[0] diff_mean_num_non0 = sum(0.5 tanh(5w)+0.5)/B, out[1] mean_num_non0 = count(w>0.05)/B,
+ * out[2] mean_w, out[3] max_w, out[4] min_w, out[5] mean_all_pts = count(x!=0 && y!=0)/B,
+ * out[6] number of real points.  partial: B*8 floats of workspace; out: 8 floats. */
+int mmk_weight_stats(const float *weights /*B,N*/, const float *pc /*B,N,pc_cols*/, int32_t B, int32_t N,
+                     int32_t pc_cols, float *partial, float *out, void *stream);
+
 int mmk_bev_raster(const float *pc /*B,M,pc_cols*/, int32_t B, int32_t M, int32_t pc_cols,
                    int32_t W, float cart_resolution, float *bev /*B,W,W*/, void *stream);
 

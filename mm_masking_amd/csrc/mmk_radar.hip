@@ -374,6 +374,76 @@ __global__ void bev_centre_kernel(float *__restrict__ bev, int B, int W)
     if (b < B) bev[(size_t)b * W * W + (size_t)(W / 2) * W + (W / 2)] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------
+// Statistics of extract_weights (radar_utils.py:130-138) and the point count the policy logs
+// (icp_weight_policy.py:209-212) in two launches instead of ~25 small reductions: one block per scan
+// forms its partial sums in a fixed order, one wave combines the scans in index order (deterministic).
+// out[0] = sum_real(0.5 tanh(5 w) + 0.5) / B     (diff_mean_num_non0)
+// out[1] = count(w > 0.05 & real) / B            (mean_num_non0)
+// out[2] = sum_real(w) / n_real                  (mean_w; NaN when no real point, as torch.mean of nothing)
+// out[3] = max_real(w), out[4] = min_real(w)     (-inf / +inf when no real point)
+// out[5] = count(x != 0 & y != 0) / B            (mean_all_pts)
+// out[6] = n_real
+constexpr int WS_NPART = 8;
+
+__global__ __launch_bounds__(256) void weight_stats_partial_kernel(const float *__restrict__ w, const float *__restrict__ pc, int N,
+                                                                   int cols, float *__restrict__ part)
+{
+    __shared__ float red[4][WS_NPART];
+    const int b = blockIdx.x;
+    float soft = 0.f, cnt = 0.f, sum = 0.f, mx = -INFINITY, mn = INFINITY, nz = 0.f, nr = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float *p = pc + ((size_t)b * N + n) * cols;
+        const float x = p[0], y = p[1];
+        const float v = w[(size_t)b * N + n];
+        const bool real = !(x == 0.0f && y == 0.0f);
+        if (real) {
+            soft += 0.5f * tanhf(5.0f * v) + 0.5f;
+            cnt += (v > 0.05f) ? 1.f : 0.f;
+            sum += v;
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+            nr += 1.f;
+        }
+        nz += (x != 0.0f && y != 0.0f) ? 1.f : 0.f;
+    }
+    float vals[WS_NPART] = {soft, cnt, sum, mx, mn, nz, nr, 0.f};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < WS_NPART; ++i) {
+            const float o = __shfl_down(vals[i], off, 64);
+            vals[i] = (i == 3) ? fmaxf(vals[i], o) : (i == 4) ? fminf(vals[i], o) : vals[i] + o;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < WS_NPART; ++i) red[wv][i] = vals[i];
+    __syncthreads();
+    if (threadIdx.x < WS_NPART) {
+        const int i = threadIdx.x;
+        float t = red[0][i];
+        for (int k = 1; k < 4; ++k) t = (i == 3) ? fmaxf(t, red[k][i]) : (i == 4) ? fminf(t, red[k][i]) : t + red[k][i];
+        part[(size_t)b * WS_NPART + i] = t;
+    }
+}
+
+__global__ void weight_stats_final_kernel(const float *__restrict__ part, int B, float *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= WS_NPART) return;
+    float t = part[i], nr = part[6];
+    for (int b = 1; b < B; ++b) {
+        const float o = part[(size_t)b * WS_NPART + i];
+        t = (i == 3) ? fmaxf(t, o) : (i == 4) ? fminf(t, o) : t + o;
+        nr += part[(size_t)b * WS_NPART + 6];
+    }
+    if (i == 0 || i == 1 || i == 5) t = t / (float)B;
+    if (i == 2) t = t / nr;
+    out[i] = t;
+}
+
 struct PeakWs {
     int32_t *row_count, *row_off, *total, *mrow;
     float *mval;
@@ -490,6 +560,19 @@ extern "C" int mmk_sample_weights_bwd(const float *grad_weights, const float *pc
     MMK_CHECK_HIP(hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * H * W, st));
     hipLaunchKernelGGL(sample_weights_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, grad_weights, pc, N, pc_cols,
                        H, W, cart_pixel_width, cart_resolution, grad_mask);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_weight_stats(const float *weights, const float *pc, int32_t B, int32_t N, int32_t pc_cols, float *partial,
+                                float *out, void *stream)
+{
+    MMK_REQUIRE(weights && pc && partial && out, "mmk_weight_stats: NULL pointer");
+    MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2, "mmk_weight_stats: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(weight_stats_partial_kernel, dim3(B), dim3(256), 0, st, weights, pc, N, pc_cols, partial);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, B, out);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

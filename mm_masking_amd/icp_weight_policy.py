@@ -20,7 +20,7 @@ import torch.nn as nn
 from torch.nn import ModuleList
 
 from .dICP.ICP import ICP
-from .radar_utils import extract_weights, form_cart_range_angle_grid, form_polar_range_grid
+from .radar_utils import _extract_weights_stats, extract_weights, form_cart_range_angle_grid, form_polar_range_grid
 
 
 def weights_init(m):
@@ -190,13 +190,14 @@ class LearnICPWeightPolicy(nn.Module):
         if mask_only:
             return weight_mask
 
-        weights, diff_mean_num_non0, mean_num_non0, mean_w, max_w, min_w = extract_weights(weight_mask, scan_pc_raw)
+        (weights, diff_mean_num_non0, mean_num_non0, mean_w, max_w, min_w), stats = \
+            _extract_weights_stats(weight_mask, scan_pc_raw)
         self.mean_num_pts = mean_num_non0
         self.max_w = max_w
         self.min_w = min_w
         self.mean_w = mean_w
-        non0_pts = (scan_pc_raw[:, :, 0] != 0.0) * (scan_pc_raw[:, :, 1] != 0.0)
-        self.mean_all_pts = torch.sum(non0_pts) / scan_pc_raw.shape[0]
+        # points with x != 0 and y != 0, per scan (icp_weight_policy.py:209-212): same fused pass
+        self.mean_all_pts = stats[5]
 
         scan_pc_filt = batch_scan["filtered_pc"].to(self.device)
 

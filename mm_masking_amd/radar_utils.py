@@ -254,29 +254,53 @@ class _SampleWeights(torch.autograd.Function):
         return gmask, None, None, None
 
 
-def extract_weights(mask, scan_pc):
-    """radar_utils.py:108-140 -> (weights (B,N), diff_mean_num_non0, mean_num_non0,
-    mean_w, max_w, min_w).  The statistics are the reference's, evaluated with
-    masked reductions instead of boolean indexing so that no host sync occurs."""
+class _WeightStats(torch.autograd.Function):
+    """The statistics of extract_weights (radar_utils.py:130-138) in one pass (mmk_weight_stats).
+    Only diff_mean_num_non0 carries a gradient (d/dw of sum(0.5 tanh(5w) + 0.5) / B over real points)."""
+
+    @staticmethod
+    def forward(ctx, weights, pc):
+        B, N = weights.shape
+        part = torch.empty(B * 8, dtype=torch.float32, device=weights.device)
+        out = torch.empty(8, dtype=torch.float32, device=weights.device)
+        w = weights.contiguous()
+        _lib.check(_lib.lib().mmk_weight_stats(_lib.ptr(w), _lib.ptr(pc), B, N, pc.shape[2], _lib.ptr(part), _lib.ptr(out),
+                                               _lib.stream_ptr(weights.device)))
+        ctx.save_for_backward(w, pc)
+        diff = out[0].clone()
+        ctx.mark_non_differentiable(out)
+        return diff, out
+
+    @staticmethod
+    def backward(ctx, g_diff, _g_stats):
+        if g_diff is None:
+            return None, None
+        w, pc = ctx.saved_tensors
+        real = ~((pc[:, :, 0] == 0.0) & (pc[:, :, 1] == 0.0))
+        t = torch.tanh(5 * w)
+        return g_diff * (2.5 / w.shape[0]) * (1 - t * t) * real, None
+
+
+def _extract_weights_stats(mask, scan_pc):
+    """extract_weights plus the raw statistics vector of mmk_weight_stats (the policy takes its
+    mean_all_pts from it)."""
     dev = _hip_device(mask)
     m = mask if (mask.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous()) else \
         mask.to(device=dev, dtype=torch.float32).contiguous()
     pc = _lib.dev_f32(scan_pc, dev)
     # point_to_cart_idx's defaults (0.2384 m, 640 px) whatever the mask's shape: radar_utils.py:112
     weights = _SampleWeights.apply(m, pc, 0.2384, 640)
-    fake = (pc[:, :, 0] == 0.0) & (pc[:, :, 1] == 0.0)
-    real = ~fake
-    wd = weights.detach()
-    nb = weights.shape[0]
-    mean_num_non0 = ((wd > 0.05) & real).sum() / nb
-    n_real = real.sum()
-    mean_w = (wd * real).sum() / n_real
-    max_w = torch.where(real, wd, torch.full_like(wd, -float("inf"))).max()
-    min_w = torch.where(real, wd, torch.full_like(wd, float("inf"))).min()
-    diff_mean_num_non0 = ((0.5 * torch.tanh(5 * weights) + 0.5) * real).sum() / nb
+    diff_mean_num_non0, st = _WeightStats.apply(weights, pc)
     if not mask.is_cuda:
         weights = weights.to(mask.device)
-    return weights, diff_mean_num_non0, mean_num_non0, mean_w, max_w, min_w
+    return (weights, diff_mean_num_non0, st[1], st[2], st[3], st[4]), st
+
+
+def extract_weights(mask, scan_pc):
+    """radar_utils.py:108-140 -> (weights (B,N), diff_mean_num_non0, mean_num_non0,
+    mean_w, max_w, min_w).  The statistics are the reference's, formed over the real points in one
+    fused pass (no boolean indexing, no host sync)."""
+    return _extract_weights_stats(mask, scan_pc)[0]
 
 
 # ----------------------------------------------------------------------------- R10

@@ -233,7 +233,9 @@ def generate_baseline(model, iterator, baseline_type="train", device="cpu",
 def make_optimizer(policy, params):
     """train_icp_weights.py:462-465."""
     if params["optimizer"] == "adam":
-        return torch.optim.Adam(policy.parameters(), lr=params["learning_rate"])
+        # the same update rule; on the GPU all 46 tensors in one launch instead of seven foreach passes
+        fused = all(p.is_cuda for p in policy.parameters())
+        return torch.optim.Adam(policy.parameters(), lr=params["learning_rate"], fused=fused)
     return torch.optim.SGD(policy.parameters(), lr=params["learning_rate"], nesterov=True, momentum=1.0)
 
 

@@ -164,6 +164,34 @@ def test_extract_weights_non_square_mask(golden_dir, tag):
     np.testing.assert_allclose(mt.grad.cpu().numpy(), want, atol=3e-5)
 
 
+def test_weight_stats_fused_pass():
+    """mmk_weight_stats against the plain tensor expressions of radar_utils.py:130-138 and
+    icp_weight_policy.py:209-212, including the gradient of diff_mean_num_non0."""
+    g = torch.Generator().manual_seed(4)
+    B, N = 3, 700
+    pc = (torch.rand(B, N, 3, generator=g) * 120 - 60)
+    pc[:, 600:, :] = 0.0                    # padded rows
+    pc[0, 5, 0] = 0.0                       # x == 0 only: real for the weights, not counted by mean_all_pts
+    pc = pc.to(DEV)
+    mask = torch.rand(B, 640, 640, generator=g).to(DEV).requires_grad_(True)
+    (w, dmn, mn, mean_w, max_w, min_w), st = ru._extract_weights_stats(mask, pc)
+    real = ~((pc[:, :, 0] == 0) & (pc[:, :, 1] == 0))
+    wd = w.detach()
+    assert abs(mn.item() - ((wd > 0.05) & real).sum().item() / B) < 1e-6 * N
+    assert abs(mean_w.item() - wd[real].mean().item()) < 1e-6
+    assert max_w.item() == wd[real].max().item() and min_w.item() == wd[real].min().item()
+    assert abs(st[5].item() - ((pc[:, :, 0] != 0) & (pc[:, :, 1] != 0)).sum().item() / B) < 1e-6 * N
+    assert st[6].item() == real.sum().item()
+    dmn.backward()
+    got = mask.grad.clone()
+    mask.grad = None
+    w2 = ru._SampleWeights.apply(mask, pc, 0.2384, 640)
+    ref = ((0.5 * torch.tanh(5 * w2) + 0.5) * real).sum() / B
+    assert abs(ref.item() - dmn.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    ref.backward()
+    assert (got - mask.grad).abs().max().item() < 1e-6
+
+
 def test_bev_golden_and_point_idx(golden_dir):
     g = _load(golden_dir, "radar_points.npz")
     bev = ru.extract_bev_from_pts(_g(g["bev_pts"])).cpu().numpy()
