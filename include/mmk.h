@@ -239,11 +239,17 @@ int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int
 
 /* First conv of the network (encoder.0.0): fp32 NCHW input (B,cin,H,W), cin = 1..4
  * (fft | cfar | range channels, icp_weight_policy.py:84), W[8][cin][3][3], + bias + ReLU ->
- * bf16 (B,H,W,8).  _wgrad: dW[8][cin][3][3] += , db[8] += (g = grad w.r.t. the pre-activation). */
-int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, int32_t B, int32_t H,
-                   int32_t Wd, void *y, void *stream);
-int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, int32_t B, int32_t H, int32_t Wd,
-                         float *dW, float *db, void *stream);
+ * bf16 (B,H,W,8).  _wgrad: dW[8][cin][3][3] += , db[8] += (g = grad w.r.t. the pre-activation).
+ * pre (may be NULL): 2 floats per input channel (offset, reciprocal scale); the kernels then read
+ * (x - offset) * rscale — the policy's per-channel min-max normalisation
+ * (icp_weight_policy.py:151-155) applied while loading.  mmk_channel_minmax fills pre with
+ * (min, 1 / (max - min)) over (B,H,W) per channel; part: C*128 floats of workspace. */
+int mmk_channel_minmax(const float *x /*B,C,hw*/, int32_t B, int32_t C, int64_t hw, float *part,
+                       float *pre /*C*2*/, void *stream);
+int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre,
+                   int32_t B, int32_t H, int32_t Wd, void *y, void *stream);
+int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B,
+                         int32_t H, int32_t Wd, float *dW, float *db, void *stream);
 
 /* nn.MaxPool2d(2,2) on NHWC bf16 (icp_weight_policy.py:122-123).  _bwd fuses the backward of
  * the preceding Dropout(ReLU(.)): gz = route(gy) * (d > 0 ? scale : 0), d = the pooled tensor's
@@ -265,6 +271,17 @@ int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t 
 int mmk_final_fwd(const void *x, const float *w, const float *bias, int64_t npix, float *mask, void *stream);
 int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
                   void *gx, float *dW, float *db, void *stream);
+/* mask_n = mask / amax(mask over the image) per image (icp_weight_policy.py:192-193), amax (B) out;
+ * part: B*64 floats of workspace. */
+int mmk_mask_normalize(const float *mask /*B,npix_per*/, int32_t B, int64_t npix_per, float *part,
+                       float *mask_n, float *amax, void *stream);
+/* mmk_final_bwd for a mask that went through mmk_mask_normalize: gmask_n is the gradient w.r.t.
+ * mask_n; the adjoint of the division and of amax (spread evenly over tied maxima, as torch.amax)
+ * is applied on the fly.  part: B*128 floats, coef: 2*B floats of workspace. */
+int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n,
+                             const float *amax, const float *gmask_n, int32_t B, int64_t npix_per,
+                             float scale, float *part, float *coef, void *gx, float *dW, float *db,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -98,14 +98,18 @@ def _declare(lib):
         "mmk_conv3x3_wgrad_unpack_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_slices": (i32, [i32, i32, i32, i32, i32, i32]),
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
-        "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
-        "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
+        "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp]),
+        "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
+        "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_maxpool2_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_upsample_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_upsample_bwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, f32, c_vp, c_vp]),
         "mmk_final_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
         "mmk_final_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, f32, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_mask_normalize": (ctypes.c_int, [c_vp, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, c_vp, c_vp,
+                                                    c_vp, c_vp, c_vp, c_vp]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
         "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,

@@ -1730,9 +1730,12 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
 // ------------------------------------------------------------------------------------------
 // First layer: fp32 NCHW input with 1..4 channels -> 8 channels NHWC bf16 (+bias, ReLU).
 // 72..288 FMAs per pixel: plain VALU, HBM-bound.
+// pre (optional, 2 floats per input channel: offset, 1/scale): the input is (x - offset) * (1/scale), the
+// policy's per-channel min-max normalisation (icp_weight_policy.py:151-155) applied while loading; the zero
+// padding is of the normalised image.
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
-                                                         const float *__restrict__ bias, int B, int H, int W,
-                                                         bf16 *__restrict__ y)
+                                                         const float *__restrict__ bias, const float *__restrict__ pre, int B, int H,
+                                                         int W, bf16 *__restrict__ y)
 {
     __shared__ float ws[8 * 4 * 9 + 8];
     for (int i = threadIdx.x; i < 8 * CIN * 9; i += blockDim.x) ws[i] = Wt[i];
@@ -1746,11 +1749,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
         for (int co = 0; co < 8; ++co) acc[co] = ws[8 * 4 * 9 + co];
         for (int c = 0; c < CIN; ++c) {
             const float *xc = x + ((size_t)b * CIN + c) * H * W;
+            const float psub = pre ? pre[2 * c] : 0.f, prcp = pre ? pre[2 * c + 1] : 1.f;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
                 float v = 0.f;
-                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = xc[(size_t)y2 * W + x2];
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = (xc[(size_t)y2 * W + x2] - psub) * prcp;
                 // bf16 operands as on the MFMA path
                 v = (float)(bf16)v;
 #pragma unroll
@@ -1766,8 +1770,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 
 // dW[8][CIN][9] += sum_p g[p][co] * x[c][p+tap], db[8] += sum_p g[p][co]  (g = grad w.r.t. pre-activation)
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
-                                                               int B, int H, int W, float *__restrict__ dW,
-                                                               float *__restrict__ db)
+                                                               const float *__restrict__ pre, int B, int H, int W,
+                                                               float *__restrict__ dW, float *__restrict__ db)
 {
     __shared__ float red[4][80];
     const size_t npix = (size_t)B * H * W;
@@ -1780,12 +1784,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
             const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
             const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(g + p * 8);
             const float *xc = x + ((size_t)b * CIN + c) * H * W;
+            const float psub = pre ? pre[2 * c] : 0.f, prcp = pre ? pre[2 * c + 1] : 1.f;
             float xv[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
                 float v = 0.f;
-                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = xc[(size_t)y2 * W + x2];
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) v = (xc[(size_t)y2 * W + x2] - psub) * prcp;
                 xv[tap] = (float)(bf16)v;
             }
 #pragma unroll
@@ -1818,7 +1823,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
 // Fast paths for W % 4 == 0: one thread per 4 horizontally adjacent pixels.  The three input rows
 // are fetched as one 16-byte load + two edge scalars each (9 loads per 4 pixels instead of 36) and
 // the index arithmetic is paid once per quad.
-__device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, int x0, int H, int W, float (&v)[6])
+__device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, int x0, int H, int W, float psub, float prcp,
+                                          float (&v)[6])
 {
     if (y2 < 0 || y2 >= H) {
 #pragma unroll
@@ -1827,16 +1833,16 @@ __device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, 
     }
     const float *row = xc + (size_t)y2 * W;
     const float4 m = *reinterpret_cast<const float4 *>(row + x0);
-    v[0] = (x0 > 0) ? row[x0 - 1] : 0.f;
-    v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
-    v[5] = (x0 + 4 < W) ? row[x0 + 4] : 0.f;
+    v[0] = (x0 > 0) ? (row[x0 - 1] - psub) * prcp : 0.f;
+    v[1] = (m.x - psub) * prcp; v[2] = (m.y - psub) * prcp; v[3] = (m.z - psub) * prcp; v[4] = (m.w - psub) * prcp;
+    v[5] = (x0 + 4 < W) ? (row[x0 + 4] - psub) * prcp : 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] = (float)(bf16)v[i];       // bf16 operands as on the MFMA path
 }
 
 __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
-                                                            const float *__restrict__ bias, int B, int H, int W,
-                                                            bf16 *__restrict__ y)
+                                                            const float *__restrict__ bias, const float *__restrict__ pre, int B,
+                                                            int H, int W, bf16 *__restrict__ y)
 {
     // (weights and bias are read at wave-uniform addresses: scalar loads, operands straight from SGPRs)
     float bs[8];
@@ -1855,10 +1861,11 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
             for (int co = 0; co < 8; ++co) acc[px][co] = bs[co];
         for (int c = 0; c < CIN; ++c) {
             const float *xc = x + ((size_t)b * CIN + c) * H * W;
+            const float psub = pre ? pre[2 * c] : 0.f, prcp = pre ? pre[2 * c + 1] : 1.f;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 float v[6];
-                load_row6(xc, yy + dy - 1, x0, H, W, v);
+                load_row6(xc, yy + dy - 1, x0, H, W, psub, prcp, v);
 #pragma unroll
                 for (int co = 0; co < 8; ++co) {
 #pragma unroll
@@ -1882,8 +1889,8 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
 }
 
 __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
-                                                                  int B, int H, int W, float *__restrict__ dW,
-                                                                  float *__restrict__ db)
+                                                                  const float *__restrict__ pre, int B, int H, int W,
+                                                                  float *__restrict__ dW, float *__restrict__ db)
 {
     __shared__ float red[4][80];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1891,6 +1898,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
     const int nq = B * H * Wq;
     const int stride = gridDim.x * blockDim.x;
     for (int c = 0; c < CIN; ++c) {
+        const float psub = pre ? pre[2 * c] : 0.f, prcp = pre ? pre[2 * c + 1] : 1.f;
         float acc[80];
 #pragma unroll
         for (int i = 0; i < 80; ++i) acc[i] = 0.f;
@@ -1906,7 +1914,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
 #pragma unroll
             for (int px = 0; px < 4; ++px) go[px] = *reinterpret_cast<const bf16x8 *>(gp + px * 8);
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) load_row6(xc, yy + dy - 1, x0, H, W, vo[dy]);
+            for (int dy = 0; dy < 3; ++dy) load_row6(xc, yy + dy - 1, x0, H, W, psub, prcp, vo[dy]);
         };
         int e = blockIdx.x * blockDim.x + threadIdx.x;
         if (e < nq) fetch(e, gv, v);
@@ -2261,19 +2269,27 @@ __global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__rest
     mask[p] = 1.0f / (1.0f + expf(-acc));
 }
 
+// grid: x strides over the pixels of one image, y = image.  coef (optional, 2 floats per image) carries the
+// adjoint of the mask's amax normalisation (see mask_norm_*): the gradient w.r.t. the raw sigmoid output is
+// g / a + (m == a ? t : 0)  with a = amax, t = -(sum g m_n) / a / count(m == a).
 __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ mask, const float *__restrict__ gmask,
-                                                        size_t npix, float scale, bf16 *__restrict__ gx,
-                                                        float *__restrict__ dW, float *__restrict__ db)
+                                                        size_t npix_per, const float *__restrict__ coef, float scale,
+                                                        bf16 *__restrict__ gx, float *__restrict__ dW, float *__restrict__ db)
 {
     __shared__ float red[4][9];
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float wv8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv8[j] = (float)(bf16)w[j];
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t base = (size_t)blockIdx.y * npix_per;
+    const float na = coef ? coef[2 * blockIdx.y] : 1.0f, nt = coef ? coef[2 * blockIdx.y + 1] : 0.f;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < npix_per; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = base + q;
         const float m = mask[p];
-        const float gl = gmask[p] * m * (1.0f - m);
+        float gm = gmask[p];
+        if (coef) gm = gm / na + ((m == na) ? nt : 0.f);
+        const float gl = gm * m * (1.0f - m);
         const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * 8);
         bf16x8 o;
 #pragma unroll
@@ -2299,6 +2315,141 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__
         if (threadIdx.x < 8) atomicAdd(&dW[threadIdx.x], v);
         else atomicAdd(&db[0], v);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// mask / amax(mask over H,W) per image (icp_weight_policy.py:192-193) and its adjoint, fused around the
+// final layer: the forward is two passes (segment maxima, then the division), the backward one reduction
+// (sum of g * m_n and the number of maximal pixels: torch.amax spreads its gradient evenly over ties)
+// whose result final_bwd_kernel applies on the fly.
+constexpr int MASK_SEG = 64;           // segments (blocks) per image
+
+__device__ __forceinline__ float block_reduce_max_256(float v, float *sh /*4*/)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void mask_segmax_kernel(const float *__restrict__ mask, size_t npix_per, float *__restrict__ part)
+{
+    __shared__ float sh[4];
+    const float *m = mask + (size_t)blockIdx.y * npix_per;
+    float v = -INFINITY;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < npix_per; q += (size_t)gridDim.x * blockDim.x)
+        v = fmaxf(v, m[q]);
+    v = block_reduce_max_256(v, sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * MASK_SEG + blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float *__restrict__ mask, size_t npix_per, const float *__restrict__ part,
+                                                         float *__restrict__ mask_n, float *__restrict__ amax)
+{
+    __shared__ float sh[4];
+    const float pv = (threadIdx.x < MASK_SEG) ? part[(size_t)blockIdx.y * MASK_SEG + threadIdx.x] : -INFINITY;
+    const float a = block_reduce_max_256(pv, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) amax[blockIdx.y] = a;
+    const size_t base = (size_t)blockIdx.y * npix_per;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < npix_per; q += (size_t)gridDim.x * blockDim.x)
+        mask_n[base + q] = mask[base + q] / a;
+}
+
+__global__ __launch_bounds__(256) void mask_norm_bwd_partial_kernel(const float *__restrict__ g, const float *__restrict__ mask_n,
+                                                                    size_t npix_per, float *__restrict__ part /*B*SEG*2*/)
+{
+    __shared__ float red[4][2];
+    const size_t base = (size_t)blockIdx.y * npix_per;
+    float s = 0.f, c = 0.f;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < npix_per; q += (size_t)gridDim.x * blockDim.x) {
+        const float mn = mask_n[base + q];
+        s = __builtin_fmaf(g[base + q], mn, s);
+        c += (mn == 1.0f) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = s;
+        red[threadIdx.x >> 6][1] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        part[((size_t)blockIdx.y * MASK_SEG + blockIdx.x) * 2 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void mask_norm_bwd_final_kernel(const float *__restrict__ part, const float *__restrict__ amax, int B,
+                                           float *__restrict__ coef)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f, c = 0.f;
+    for (int k = 0; k < MASK_SEG; ++k) {
+        s += part[((size_t)b * MASK_SEG + k) * 2];
+        c += part[((size_t)b * MASK_SEG + k) * 2 + 1];
+    }
+    const float a = amax[b];
+    coef[2 * b] = a;
+    coef[2 * b + 1] = (c > 0.f) ? -(s / a) / c : 0.f;
+}
+
+// Per-channel minimum / maximum of an fp32 NCHW tensor over (B,H,W) -> pre[2c] = min, pre[2c+1] = 1 / (max - min):
+// the offset and reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155),
+// consumed by the first-layer kernels while they load.
+__global__ __launch_bounds__(256) void channel_minmax_partial_kernel(const float *__restrict__ x, int B, int C, size_t hw,
+                                                                     float *__restrict__ part /*C*SEG*2*/)
+{
+    __shared__ float shn[4], shx[4];
+    const int c = blockIdx.y;
+    float mn = INFINITY, mx = -INFINITY;
+    const bool vec = (hw & 3) == 0;
+    for (int b = 0; b < B; ++b) {
+        const float *xc = x + ((size_t)b * C + c) * hw;
+        if (vec) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(xc);
+            for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < hw / 4; q += (size_t)gridDim.x * blockDim.x) {
+                const float4 v = x4[q];
+                mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+                mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+            }
+        } else {
+            for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < hw; q += (size_t)gridDim.x * blockDim.x) {
+                mn = fminf(mn, xc[q]);
+                mx = fmaxf(mx, xc[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off, 64));
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        shn[threadIdx.x >> 6] = mn;
+        shx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)c * MASK_SEG + blockIdx.x) * 2] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+        part[((size_t)c * MASK_SEG + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
+    }
+}
+
+__global__ void channel_minmax_final_kernel(const float *__restrict__ part, int C, float *__restrict__ pre)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < MASK_SEG; ++k) {
+        mn = fminf(mn, part[((size_t)c * MASK_SEG + k) * 2]);
+        mx = fmaxf(mx, part[((size_t)c * MASK_SEG + k) * 2 + 1]);
+    }
+    pre[2 * c] = mn;
+    pre[2 * c + 1] = 1.0f / (mx - mn);
 }
 
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
@@ -2446,40 +2597,52 @@ extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t
 
 static unsigned nblk(size_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
-extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, int32_t B, int32_t H,
-                              int32_t Wd, void *y, void *stream)
+extern "C" int mmk_channel_minmax(const float *x, int32_t B, int32_t C, int64_t hw, float *part, float *pre, void *stream)
+{
+    MMK_REQUIRE(x && part && pre && B >= 1 && C >= 1 && C <= 65535 && hw >= 1, "mmk_channel_minmax: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(channel_minmax_partial_kernel, dim3(MASK_SEG, C), dim3(256), 0, st, x, B, C, (size_t)hw, part);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(channel_minmax_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, C, pre);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre, int32_t B,
+                              int32_t H, int32_t Wd, void *y, void *stream)
 {
     MMK_REQUIRE(x && W && y, "mmk_conv_first: NULL pointer");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first: bad shape (cin must be 1..4)");
     const size_t npix = (size_t)B * H * Wd;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
         const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 4096);
-        hipLaunchKernelGGL(conv_first_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, B, H, Wd, (bf16 *)y);
+        hipLaunchKernelGGL(conv_first_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd,
+                           (bf16 *)y);
         MMK_LAUNCH_CHECK();
         return MMK_OK;
     }
     const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 8192);
-    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, B, H, Wd, (bf16 *)y);
+    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd, (bf16 *)y);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
 
-extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, int32_t B, int32_t H, int32_t Wd,
-                                    float *dW, float *db, void *stream)
+extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B, int32_t H,
+                                    int32_t Wd, float *dW, float *db, void *stream)
 {
     MMK_REQUIRE(x && g && dW, "mmk_conv_first_wgrad: NULL pointer");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first_wgrad: bad shape");
     const size_t npix = (size_t)B * H * Wd;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
         const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 512);   // 80 same-address float atomics per block: few blocks
-        hipLaunchKernelGGL(conv_first_wgrad_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B,
-                           H, Wd, dW, db);
+        hipLaunchKernelGGL(conv_first_wgrad_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, pre,
+                           B, H, Wd, dW, db);
         MMK_LAUNCH_CHECK();
         return MMK_OK;
     }
     const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 1024);
-    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, B, H,
-                       Wd, dW, db);
+    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, pre, B,
+                       H, Wd, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2571,8 +2734,40 @@ extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, c
 {
     MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && npix >= 1, "mmk_final_bwd: bad argument");
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);   // 9 same-address atomics per block
-    hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
-                       (size_t)npix, scale, (bf16 *)gx, dW, db);
+    hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
+                       (size_t)npix, (const float *)nullptr, scale, (bf16 *)gx, dW, db);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_mask_normalize(const float *mask, int32_t B, int64_t npix_per, float *part, float *mask_n, float *amax,
+                                  void *stream)
+{
+    MMK_REQUIRE(mask && part && mask_n && amax && B >= 1 && B <= 65535 && npix_per >= 1, "mmk_mask_normalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mask_segmax_kernel, dim3(MASK_SEG, B), dim3(256), 0, st, mask, (size_t)npix_per, part);
+    MMK_LAUNCH_CHECK();
+    const unsigned bx = (unsigned)std::min<size_t>(((size_t)npix_per + 1023) / 1024, 256);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(bx, B), dim3(256), 0, st, mask, (size_t)npix_per, part, mask_n, amax);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n, const float *amax,
+                                        const float *gmask_n, int32_t B, int64_t npix_per, float scale, float *part, float *coef,
+                                        void *gx, float *dW, float *db, void *stream)
+{
+    MMK_REQUIRE(x && w && mask && mask_n && amax && gmask_n && part && coef && gx && dW && db, "mmk_final_bwd_normalized: NULL pointer");
+    MMK_REQUIRE(B >= 1 && B <= 65535 && npix_per >= 1, "mmk_final_bwd_normalized: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mask_norm_bwd_partial_kernel, dim3(MASK_SEG, B), dim3(256), 0, st, gmask_n, mask_n, (size_t)npix_per, part);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mask_norm_bwd_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, part, amax, B, coef);
+    MMK_LAUNCH_CHECK();
+    // ~512 blocks in all (9 same-address atomics per block)
+    const unsigned per = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)npix_per + 255) / 256, (512 + B - 1) / B));
+    hipLaunchKernelGGL(final_bwd_kernel, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
+                       scale, (bf16 *)gx, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

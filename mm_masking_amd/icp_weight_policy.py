@@ -118,7 +118,9 @@ class LearnICPWeightPolicy(nn.Module):
         return nn.Sequential(*modules)
 
     # ------------------------------------------------------------------ U1-U4
-    def _network_input(self, fft_data, fft_cfar):
+    def _network_input(self, fft_data, fft_cfar, normalize=True):
+        """icp_weight_policy.py:136-159.  ``normalize=False`` stops before the per-channel normalisation
+        (the hand-written first layer applies the min-max form while it loads the image)."""
         input_data = None
         if self.network_inputs["fft"]:
             input_data = fft_data.unsqueeze(1)
@@ -130,6 +132,11 @@ class LearnICPWeightPolicy(nn.Module):
             input_data = torch.cat([input_data, range_stack], dim=1)
         if self.log_transform:
             input_data = torch.log(input_data + 1e-6)
+        if not normalize:
+            return input_data
+        return self._normalize_channels(input_data)
+
+    def _normalize_channels(self, input_data):
         chans = []
         for c in range(input_data.shape[1]):
             xc = input_data[:, c, :, :]
@@ -169,21 +176,32 @@ class LearnICPWeightPolicy(nn.Module):
         map_pc = batch_map["pc"].to(self.device)
 
         if override_mask is None:
-            net_in = self._network_input(fft_data, fft_cfar)
+            raw_in = self._network_input(fft_data, fft_cfar, normalize=False)
             # any image of at least 32 x 32 (five floor-rounding poolings leave >= 1 pixel): the Cartesian
             # 640 x 640 grid and the polar 400 x 3360 one (network_input_type "polar") alike
-            use_hip = (self.unet_backend == "hip" and net_in.is_cuda and not self.leaky and not self.batch_norm
-                       and net_in.shape[1] <= 4 and net_in.shape[2] >= 32 and net_in.shape[3] >= 32)
+            use_hip = (self.unet_backend == "hip" and raw_in.is_cuda and not self.leaky and not self.batch_norm
+                       and raw_in.shape[1] <= 4 and raw_in.shape[2] >= 32 and raw_in.shape[3] >= 32)
             if use_hip:
                 from . import unet_hip
                 self._step += 1
-                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step)
+                if "minmax" in self.normalize_type:
+                    # min-max normalisation folded into the first layer's loads: one min/max pass, no
+                    # normalised copy of the image
+                    net_in = raw_in.contiguous().float()
+                    pre = unet_hip.channel_minmax(net_in)
+                else:
+                    net_in, pre = self._normalize_channels(raw_in), None
+                # (the amax normalisation below rides inside the same autograd node)
+                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre)
+                normalised = self.norm_weights
             else:
-                weight_mask = self._unet(net_in)
+                weight_mask = self._unet(self._normalize_channels(raw_in))
+                normalised = False
         else:
             weight_mask = override_mask.to(self.device)
+            normalised = False
 
-        if self.norm_weights:
+        if self.norm_weights and not normalised:
             weight_mask = weight_mask / torch.amax(weight_mask, dim=(1, 2), keepdim=True)
         if binary:
             weight_mask = torch.where(weight_mask > 0.5, 1.0, 0.0)

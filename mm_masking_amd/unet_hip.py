@@ -158,12 +158,23 @@ def _sp(dev):
     return _lib.stream_ptr(dev)
 
 
-def conv_first(x, w, b):
-    """x fp32 (B,cin,H,W) -> bf16 (B,H,W,8), + bias + ReLU (encoder.0.0)."""
+def conv_first(x, w, b, pre=None):
+    """x fp32 (B,cin,H,W) -> bf16 (B,H,W,8), + bias + ReLU (encoder.0.0).  ``pre`` (cin,2): per-channel
+    (offset, reciprocal scale) applied to x while loading (see channel_minmax)."""
     B, cin, H, W = x.shape
     y = torch.empty(B, H, W, 8, dtype=BF16, device=x.device)
-    _lib.check(_lib.lib().mmk_conv_first(_p(x), cin, _p(w), _p(b), B, H, W, _p(y), _sp(x.device)))
+    _lib.check(_lib.lib().mmk_conv_first(_p(x), cin, _p(w), _p(b), _p(pre), B, H, W, _p(y), _sp(x.device)))
     return y
+
+
+def channel_minmax(x):
+    """(min, 1 / (max - min)) per channel of fp32 (B,C,H,W) over (B,H,W) -> (C,2) fp32: the offset and
+    reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155)."""
+    B, C, H, W = x.shape
+    part = torch.empty(C * 128, dtype=torch.float32, device=x.device)
+    pre = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mmk_channel_minmax(_p(x), B, C, H * W, _p(part), _p(pre), _sp(x.device)))
+    return pre
 
 
 def maxpool2(x):
@@ -222,7 +233,7 @@ class _UNet(torch.autograd.Function):
     backward is the hand-scheduled reverse pass (no autograd graph inside)."""
 
     @staticmethod
-    def forward(ctx, x, drop_p, seed, training, *params):
+    def forward(ctx, x, pre, drop_p, seed, training, norm, *params):
         dev = x.device
         x = x.contiguous().float()
         B, cin, H, W = x.shape
@@ -246,7 +257,7 @@ class _UNet(torch.autograd.Function):
         saved = {}
         # ---- encoder
         w0, b0 = wb(0)
-        a = conv_first(x, w0.float().contiguous(), b0.float().contiguous())
+        a = conv_first(x, w0.float().contiguous(), b0.float().contiguous(), pre)
         w1, b1 = wb(1)
         d = conv3x3(a, pk(1), 8, bias=b1, relu=True, drop_p=p_drop, seed=next_seed())
         saved["e0"] = (a, d)
@@ -281,6 +292,7 @@ class _UNet(torch.autograd.Function):
         if DEBUG is not None:
             DEBUG["fwd"] = {"t": t, "enc": saved, "dec": dsaved}
         ctx.x = x
+        ctx.pre = pre
         ctx.t = t
         ctx.saved_enc = saved
         ctx.saved_dec = dsaved
@@ -290,6 +302,17 @@ class _UNet(torch.autograd.Function):
         ctx.mask = mask.detach()
         ctx.scale = dropout_scale(p_drop)
         ctx.n_params = len(params)
+        ctx.norm = bool(norm)
+        if ctx.norm:
+            # mask / amax(mask) per image (icp_weight_policy.py:192-193), fused around the final layer
+            npix = H * W
+            part = torch.empty(B * 64, dtype=torch.float32, device=dev)
+            mask_n = torch.empty_like(mask)
+            amax = torch.empty(B, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().mmk_mask_normalize(_p(mask), B, npix, _p(part), _p(mask_n), _p(amax), _sp(dev)))
+            ctx.mask_n = mask_n.detach()
+            ctx.amax = amax
+            return mask_n
         return mask
 
     @staticmethod
@@ -348,8 +371,14 @@ class _UNet(torch.autograd.Function):
         wf8 = W(22).float().reshape(8).contiguous()
         g_fw, g_fb = seg(44), seg(45)
         gz = torch.empty_like(d2_4)
-        _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, _p(gz), _p(g_fw),
-                                   _p(g_fb), _sp(dev)))
+        if ctx.norm:
+            npix = gmask.shape[1] * gmask.shape[2]
+            ws = torch.empty(B * 130, dtype=torch.float32, device=dev)
+            _lib.check(L.mmk_final_bwd_normalized(_p(d2_4), _p(wf8), _p(ctx.mask), _p(ctx.mask_n), _p(ctx.amax), _p(gmask), B, npix,
+                                                  s, _p(ws[:B * 128]), _p(ws[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _sp(dev)))
+        else:
+            _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, _p(gz), _p(g_fw),
+                                       _p(g_fb), _sp(dev)))
         dbg = DEBUG
         if dbg is not None:
             dbg["gz_d2_4"] = gz
@@ -407,7 +436,8 @@ class _UNet(torch.autograd.Function):
         wgrad(1, a0, gz_d0)
         gz_a0 = conv3x3(gz_d0, pkt(1), 8, relu_src=a0, scale=1.0)
         g_w0, g_b0 = seg(0).view(8, cin0, 3, 3), seg(1)
-        _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0), _sp(dev)))
+        _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), _p(ctx.pre), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0),
+                                          _sp(dev)))
         # ---- assemble parameter gradients in input order
         out = [g_w0, g_b0]
         items = [(part[k], W(k).shape[0], W(k).shape[1], dB[k]) if k in part else dWt[k] for k in range(1, 22)]
@@ -415,9 +445,11 @@ class _UNet(torch.autograd.Function):
             out += [gw, dB[k]]
         out += [g_fw.reshape(1, 8, 1, 1), g_fb]
         out = [g.to(p.dtype) for g, p in zip(out, P)]
-        return (None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None) + tuple(out)
 
 
-def unet_mask(module, x, training, seed):
-    """sigmoid mask (B,H,W) fp32 of the module's network on fp32 NCHW input x."""
-    return _UNet.apply(x, float(module.dropout), int(seed), bool(training), *param_list(module))
+def unet_mask(module, x, training, seed, norm=False, pre=None):
+    """sigmoid mask (B,H,W) fp32 of the module's network on fp32 NCHW input x; ``norm``: divided by its
+    per-image maximum (the policy's ``norm_weights``), inside the same autograd node; ``pre`` (C,2): the
+    input is (x - pre[c,0]) * pre[c,1], applied by the first layer while it loads x."""
+    return _UNet.apply(x, pre, float(module.dropout), int(seed), bool(training), bool(norm), *param_list(module))

@@ -265,11 +265,31 @@ def test_aux_kernels_vs_torch():
         pre.backward(gz.float().permute(0, 3, 1, 2))
         dw = torch.zeros(8, 3, 3, 3, device=DEV)
         db = torch.zeros(8, device=DEV)
-        _lib.check(_lib.lib().mmk_conv_first_wgrad(ctypes.c_void_p(x.data_ptr()), 3, ctypes.c_void_p(gz.data_ptr()), 2, 20, wd,
+        _lib.check(_lib.lib().mmk_conv_first_wgrad(ctypes.c_void_p(x.data_ptr()), 3, ctypes.c_void_p(gz.data_ptr()), None, 2, 20, wd,
                                                    ctypes.c_void_p(dw.data_ptr()), ctypes.c_void_p(db.data_ptr()),
                                                    _lib.stream_ptr(DEV)))
         assert (dw - wq.grad).abs().max().item() < 2e-3 * wq.grad.abs().max().item() + 1e-3
         assert (db - bq.grad).abs().max().item() < 2e-3 * bq.grad.abs().max().item() + 1e-3
+        # min-max normalisation folded into the loads (icp_weight_policy.py:151-155): channel_minmax
+        # gives (min, 1 / (max - min)) per channel; the result matches the layer on the normalised image
+        xs = x * torch.tensor([3.0, 0.5, 40.0], device=DEV).view(1, 3, 1, 1) + torch.tensor([-1.0, 2.0, 7.0], device=DEV).view(1, 3, 1, 1)
+        prm = uh.channel_minmax(xs)
+        mn, mx = xs.amin(dim=(0, 2, 3)), xs.amax(dim=(0, 2, 3))
+        assert torch.equal(prm[:, 0], mn) and torch.equal(prm[:, 1], 1.0 / (mx - mn))
+        xn = (xs - mn.view(1, 3, 1, 1)) / (mx - mn).view(1, 3, 1, 1)
+        y_ref, y_pre = uh.conv_first(xn, w, b), uh.conv_first(xs, w, b, prm)
+        assert (y_pre.float() - y_ref.float()).abs().max().item() < 0.02      # (multiply by the reciprocal vs divide)
+        dw2 = torch.zeros(8, 3, 3, 3, device=DEV)
+        db2 = torch.zeros(8, device=DEV)
+        _lib.check(_lib.lib().mmk_conv_first_wgrad(ctypes.c_void_p(xs.data_ptr()), 3, ctypes.c_void_p(gz.data_ptr()),
+                                                   ctypes.c_void_p(prm.data_ptr()), 2, 20, wd, ctypes.c_void_p(dw2.data_ptr()),
+                                                   ctypes.c_void_p(db2.data_ptr()), _lib.stream_ptr(DEV)))
+        dw3 = torch.zeros(8, 3, 3, 3, device=DEV)
+        db3 = torch.zeros(8, device=DEV)
+        _lib.check(_lib.lib().mmk_conv_first_wgrad(ctypes.c_void_p(xn.data_ptr()), 3, ctypes.c_void_p(gz.data_ptr()), None, 2, 20, wd,
+                                                   ctypes.c_void_p(dw3.data_ptr()), ctypes.c_void_p(db3.data_ptr()),
+                                                   _lib.stream_ptr(DEV)))
+        assert (dw2 - dw3).abs().max().item() < 2e-3 * dw3.abs().max().item() + 1e-3 and torch.allclose(db2, db3)
     # max pool fwd / bwd (with the fused relu+dropout factor)
     d = F.relu(torch.randn(2, 16, 12, 20, generator=g)).to(DEV)
     dn = _nhwc(d)
@@ -480,3 +500,27 @@ def test_unet_hip_close_to_fp32_module():
     assert num <= (0.12 ** 2) * den
     for a, b in zip(got, gref):
         assert F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.7   # (worst tensor: a deep bias, ~0.8)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 50, 84)])
+def test_unet_hip_fused_mask_normalisation(B, H, W):
+    """norm=True (mask / amax per image inside the network's autograd node: mmk_mask_normalize,
+    mmk_final_bwd_normalized) against the same network followed by the tensor expression of
+    icp_weight_policy.py:192-193 under autograd."""
+    model = _policy(0.0, torch.float32)
+    model.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, 1, H, W, generator=g).to(DEV)
+    gsel = torch.randn(B, H, W, generator=g).to(DEV)
+    raw = uh.unet_mask(model, x, training=True, seed=1)
+    ref = raw / torch.amax(raw, dim=(1, 2), keepdim=True)
+    (ref * gsel).sum().backward()
+    want = [p.grad.clone() for p in uh.param_list(model)]
+    model.zero_grad()
+    out = uh.unet_mask(model, x, training=True, seed=1, norm=True)
+    assert torch.equal(out, ref)                           # same division, same maximum
+    assert float(out.amax()) == 1.0
+    (out * gsel).sum().backward()
+    for (n, _), a, b in zip(model.named_parameters(), [p.grad for p in uh.param_list(model)], want):
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        assert rel < 2e-3, (n, rel)     # bf16 gradient tensors downstream amplify the fp32 summation-order difference
