@@ -235,8 +235,12 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restr
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < A; i += blockDim.x) laz[i] = az[(size_t)b * A + i];
     __syncthreads();
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= W * W) return;
+    // a block is a 32 x 8 patch of the Cartesian image (compact footprint in the polar one: the taps of
+    // neighbouring lanes share cache lines), not a 256-pixel strip of one row
+    const int tiles_x = (W + 31) >> 5;
+    const int px = (blockIdx.x % tiles_x) * 32 + (threadIdx.x & 31), py = (blockIdx.x / tiles_x) * 8 + (threadIdx.x >> 5);
+    if (px >= W || py >= W) return;
+    const int pix = py * W + px;
     const float rng = rgrid[pix], ang = agrid[pix];
     float u = (rng - half_res) / res;
     float v;
@@ -529,7 +533,7 @@ extern "C" int mmk_polar_to_cart(const float *polar, const float *azimuths, cons
     MMK_REQUIRE(B >= 1 && A >= 2 && R >= 2 && W >= 1, "mmk_polar_to_cart: bad shape");
     MMK_REQUIRE((size_t)A * 4 <= 64 * 1024, "mmk_polar_to_cart: too many azimuths (%d)", A);
     const float half_res = (float)((double)radar_resolution / 2.0);
-    hipLaunchKernelGGL(polar_to_cart_kernel, dim3((W * W + 255) / 256, B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
+    hipLaunchKernelGGL(polar_to_cart_kernel, dim3(((W + 31) / 32) * ((W + 7) / 8), B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
                        polar, azimuths, range_grid, angle_grid, A, R, W, radar_resolution, half_res,
                        interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart);
     MMK_LAUNCH_CHECK();

@@ -2271,7 +2271,7 @@ __global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__rest
 
 // grid: x strides over the pixels of one image, y = image.  coef (optional, 2 floats per image) carries the
 // adjoint of the mask's amax normalisation (see mask_norm_*): the gradient w.r.t. the raw sigmoid output is
-// g / a + (m == a ? t : 0)  with a = amax, t = -(sum g m_n) / a / count(m == a).
+// g * (1 / a) + (m == a ? t : 0)  with a = amax, t = -(sum g m_n) / a / count(m == a).
 __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ mask, const float *__restrict__ gmask,
                                                         size_t npix_per, const float *__restrict__ coef, float scale,
@@ -2284,11 +2284,12 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__
     for (int j = 0; j < 8; ++j) wv8[j] = (float)(bf16)w[j];
     const size_t base = (size_t)blockIdx.y * npix_per;
     const float na = coef ? coef[2 * blockIdx.y] : 1.0f, nt = coef ? coef[2 * blockIdx.y + 1] : 0.f;
+    const float rna = 1.0f / na;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < npix_per; q += (size_t)gridDim.x * blockDim.x) {
         const size_t p = base + q;
         const float m = mask[p];
         float gm = gmask[p];
-        if (coef) gm = gm / na + ((m == na) ? nt : 0.f);
+        if (coef) gm = gm * rna + ((m == na) ? nt : 0.f);
         const float gl = gm * m * (1.0f - m);
         const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * 8);
         bf16x8 o;
@@ -2400,8 +2401,10 @@ __global__ void mask_norm_bwd_final_kernel(const float *__restrict__ part, const
 // Per-channel minimum / maximum of an fp32 NCHW tensor over (B,H,W) -> pre[2c] = min, pre[2c+1] = 1 / (max - min):
 // the offset and reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155),
 // consumed by the first-layer kernels while they load.
+constexpr int MM_BLOCKS = 1024;       // blocks (and partial results) per channel
+
 __global__ __launch_bounds__(256) void channel_minmax_partial_kernel(const float *__restrict__ x, int B, int C, size_t hw,
-                                                                     float *__restrict__ part /*C*SEG*2*/)
+                                                                     float *__restrict__ part /*C*MM_BLOCKS*2*/)
 {
     __shared__ float shn[4], shx[4];
     const int c = blockIdx.y;
@@ -2434,22 +2437,36 @@ __global__ __launch_bounds__(256) void channel_minmax_partial_kernel(const float
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[((size_t)c * MASK_SEG + blockIdx.x) * 2] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
-        part[((size_t)c * MASK_SEG + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
+        part[((size_t)c * MM_BLOCKS + blockIdx.x) * 2] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+        part[((size_t)c * MM_BLOCKS + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
     }
 }
 
-__global__ void channel_minmax_final_kernel(const float *__restrict__ part, int C, float *__restrict__ pre)
+__global__ __launch_bounds__(256) void channel_minmax_final_kernel(const float *__restrict__ part, int C, float *__restrict__ pre)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float shn[4], shx[4];
+    const int c = blockIdx.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (int k = 0; k < MASK_SEG; ++k) {
-        mn = fminf(mn, part[((size_t)c * MASK_SEG + k) * 2]);
-        mx = fmaxf(mx, part[((size_t)c * MASK_SEG + k) * 2 + 1]);
+    for (int k = threadIdx.x; k < MM_BLOCKS; k += blockDim.x) {
+        mn = fminf(mn, part[((size_t)c * MM_BLOCKS + k) * 2]);
+        mx = fmaxf(mx, part[((size_t)c * MM_BLOCKS + k) * 2 + 1]);
     }
-    pre[2 * c] = mn;
-    pre[2 * c + 1] = 1.0f / (mx - mn);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off, 64));
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        shn[threadIdx.x >> 6] = mn;
+        shx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+        mx = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
+        pre[2 * c] = mn;
+        pre[2 * c + 1] = 1.0f / (mx - mn);
+    }
 }
 
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
@@ -2601,9 +2618,9 @@ extern "C" int mmk_channel_minmax(const float *x, int32_t B, int32_t C, int64_t 
 {
     MMK_REQUIRE(x && part && pre && B >= 1 && C >= 1 && C <= 65535 && hw >= 1, "mmk_channel_minmax: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(channel_minmax_partial_kernel, dim3(MASK_SEG, C), dim3(256), 0, st, x, B, C, (size_t)hw, part);
+    hipLaunchKernelGGL(channel_minmax_partial_kernel, dim3(MM_BLOCKS, C), dim3(256), 0, st, x, B, C, (size_t)hw, part);
     MMK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(channel_minmax_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, C, pre);
+    hipLaunchKernelGGL(channel_minmax_final_kernel, dim3(C), dim3(256), 0, st, part, C, pre);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

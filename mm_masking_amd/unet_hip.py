@@ -171,7 +171,7 @@ def channel_minmax(x):
     """(min, 1 / (max - min)) per channel of fp32 (B,C,H,W) over (B,H,W) -> (C,2) fp32: the offset and
     reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155)."""
     B, C, H, W = x.shape
-    part = torch.empty(C * 128, dtype=torch.float32, device=x.device)
+    part = torch.empty(C * 2048, dtype=torch.float32, device=x.device)
     pre = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mmk_channel_minmax(_p(x), B, C, H * W, _p(part), _p(pre), _sp(x.device)))
     return pre
