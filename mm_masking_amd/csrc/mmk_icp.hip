@@ -22,6 +22,7 @@ constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 1024;  // target points staged in LDS per tile
 constexpr float NN_PAD = 3.0e18f;
 constexpr int ACC_THREADS = 256;
+constexpr int PART_ROWS = 32;         // rows of block partials staged in LDS per round by the per-pair kernels
 
 __host__ __device__ constexpr int nacc(int dim) { return dim == 2 ? 9 : 27; }
 __host__ __device__ constexpr int npose(int dim) { return dim == 2 ? 6 : 12; }
@@ -635,12 +636,24 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double acc[NACC];
+    __shared__ double stage[PART_ROWS * NACC];
     const bool act = active_in[b] != 0;
-    if (lane < NACC) {
+    {
+        // the block partials, summed in index order as before; the wave fetches PART_ROWS rows at a time
+        // (coalesced, all in flight) instead of one dependent load per row and lane
         double v = 0.0;
-        if (act)
-            for (int q = 0; q < nblk; ++q) v += partials[((size_t)b * nblk + q) * NACC + lane];
-        acc[lane] = v;
+        if (act) {
+            const double *base = partials + (size_t)b * nblk * NACC;
+            for (int r0 = 0; r0 < nblk; r0 += PART_ROWS) {
+                const int nr = min(PART_ROWS, nblk - r0);
+                for (int e = lane; e < nr * NACC; e += 64) stage[e] = base[(size_t)r0 * NACC + e];
+                __syncthreads();
+                if (lane < NACC)
+                    for (int q = 0; q < nr; ++q) v += stage[q * NACC + lane];
+                __syncthreads();
+            }
+        }
+        if (lane < NACC) acc[lane] = v;
     }
     __syncthreads();
     if (lane != 0) return;
@@ -695,17 +708,26 @@ __global__ __launch_bounds__(64) void icp_bwd_pair_kernel(
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double G[16], Eb[16], X[16], M0[64], R0[64], R1[64];
+    __shared__ double stage[PART_ROWS * NP];
 
-    // full gradient w.r.t. T_{k+1}: direct part + point path of the later iteration
-    if (lane < 16) {
-        double v = Gdir_in[(size_t)b * 16 + lane];
+    // full gradient w.r.t. T_{k+1}: direct part + point path of the later iteration (the parts are
+    // added in index order; rows are fetched PART_ROWS at a time by the whole wave)
+    {
+        double v = (lane < 16) ? Gdir_in[(size_t)b * 16 + lane] : 0.0;
         const int r = lane >> 2, c = lane & 3;
         int slot = -1;
-        if (r < DIM && c < DIM) slot = r * DIM + c;
-        if (r < DIM && c == 3) slot = DIM * DIM + r;
-        if (slot >= 0)
-            for (int q = 0; q < nparts; ++q) v += pparts[((size_t)b * nparts + q) * NP + slot];
-        G[lane] = v;
+        if (lane < 16 && r < DIM && c < DIM) slot = r * DIM + c;
+        if (lane < 16 && r < DIM && c == 3) slot = DIM * DIM + r;
+        const double *base = pparts + (size_t)b * nparts * NP;
+        for (int r0 = 0; r0 < nparts; r0 += PART_ROWS) {
+            const int nr = min(PART_ROWS, nparts - r0);
+            for (int e = lane; e < nr * NP; e += 64) stage[e] = base[(size_t)r0 * NP + e];
+            __syncthreads();
+            if (slot >= 0)
+                for (int q = 0; q < nr; ++q) v += stage[q * NP + slot];
+            __syncthreads();
+        }
+        if (lane < 16) G[lane] = v;
     }
     __syncthreads();
     const bool act = (active != nullptr) && active[b] != 0;
@@ -928,16 +950,23 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
                                  float *__restrict__ out)
 {
     constexpr int NP = npose(DIM);
+    __shared__ double stage[PART_ROWS * NP];
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (lane >= 16) return;
-    double v = Gdir[(size_t)b * 16 + lane];
+    double v = (lane < 16) ? Gdir[(size_t)b * 16 + lane] : 0.0;
     const int r = lane >> 2, c = lane & 3;
     int slot = -1;
-    if (r < DIM && c < DIM) slot = r * DIM + c;
-    if (r < DIM && c == 3) slot = DIM * DIM + r;
-    if (slot >= 0)
-        for (int q = 0; q < nparts; ++q) v += pparts[((size_t)b * nparts + q) * NP + slot];
-    out[(size_t)b * 16 + lane] = (float)v;
+    if (lane < 16 && r < DIM && c < DIM) slot = r * DIM + c;
+    if (lane < 16 && r < DIM && c == 3) slot = DIM * DIM + r;
+    const double *base = pparts + (size_t)b * nparts * NP;
+    for (int r0 = 0; r0 < nparts; r0 += PART_ROWS) {
+        const int nr = min(PART_ROWS, nparts - r0);
+        for (int e = lane; e < nr * NP; e += blockDim.x) stage[e] = base[(size_t)r0 * NP + e];
+        __syncthreads();
+        if (slot >= 0)
+            for (int q = 0; q < nr; ++q) v += stage[q * NP + slot];
+        __syncthreads();
+    }
+    if (lane < 16) out[(size_t)b * 16 + lane] = (float)v;
 }
 
 // ------------------------------------------------------------------------------------------
