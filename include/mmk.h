@@ -202,7 +202,13 @@ typedef struct {
     int32_t relu;          /* forward: ReLU after the bias                                  */
     float drop_p;          /* forward: inverted dropout with this probability (0 = none)    */
     uint32_t seed;
+    void *pool_y;          /* optional bf16 (B,H/2,W/2,O1): nn.MaxPool2d(2,2) of y1 written by the same
+                              pass (forward role, single output; layers for which
+                              mmk_conv3x3_pool_fusable() returns 1), else NULL                  */
 } mmk_conv_desc;
+
+/* 1 when mmk_conv3x3 can write the 2x2 max-pool of this layer's output itself (pool_y). */
+int32_t mmk_conv3x3_pool_fusable(int32_t cin, int32_t cout, int32_t B, int32_t H, int32_t W);
 
 /* Packed bf16 element count / packing of fp32 master weights W[cout][cin][3][3].
  * transposed = 1 packs the data-gradient operator (cout -> cin, taps flipped).            */

@@ -48,7 +48,7 @@ class ConvDesc(ctypes.Structure):
                 ("y2", ctypes.c_void_p), ("relu_src2", ctypes.c_void_p), ("O2", ctypes.c_int32),
                 ("accumulate2", ctypes.c_int32), ("scale2", ctypes.c_float),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32),
-                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32)]
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p)]
 
 
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
@@ -98,6 +98,7 @@ def _declare(lib):
         "mmk_conv3x3_wgrad_unpack_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_slices": (i32, [i32, i32, i32, i32, i32, i32]),
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
+        "mmk_conv3x3_pool_fusable": (ctypes.c_int32, [i32, i32, i32, i32, i32]),
         "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp]),
         "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
         "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),

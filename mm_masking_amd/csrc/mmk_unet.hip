@@ -163,6 +163,7 @@ struct ConvArgs {
     int relu;
     float drop_p;          // forward dropout on the output (0 = none)
     unsigned seed;
+    bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
 };
 
 __device__ __forceinline__ unsigned hash_u32(unsigned x)
@@ -426,16 +427,17 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
 // native vector type: the HIP uint4 struct is copied by memcpy, which keeps a register ring in scratch
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ u32x4 g_zero16;   // zero-initialised, never written
-__device__ u32x4 g_sink16[4]; // write-only: where lanes without an output element store
+__device__ u32x4 g_sink16[8]; // write-only: where lanes without an output element store
 
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CK, int CM, int RD, bool EPI>
+template <int CK, int CM, int RD, bool EPI, bool POOL = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
+    static_assert(!(EPI && POOL), "the pooled output belongs to the forward pass (no epilogue operands)");
     constexpr int NS = ksteps(CK);
     constexpr int MT = CM / 16;
     constexpr int NT = 4;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int NST = MT * NT;                               // stores per stage
+    constexpr int NST = MT * NT + (POOL ? MT * 2 : 0);         // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
     bf16 *w_lds = in_tile + 2 * HT * WT * PK;
@@ -507,6 +509,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     int lane_pix[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) lane_pix[n] = (2 * wv + (n >> 1)) * a.W + (n & 1) * 16 + (lane & 15);
+    // POOL: 2x2 max-pool of the output in the same pass (nn.MaxPool2d(2,2) after the block's second conv,
+    // icp_weight_policy.py:122-123).  The wave's two tile rows are one pooling row: the vertical maximum is
+    // between two of its own accumulators, the horizontal one between neighbouring lanes (DPP); even lanes
+    // store 4 channels of pooled pixel (wv, 8 half + lane%16 / 2) of the tile.
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    int p_loff[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) p_loff[m][h] = (wv * Wp + h * 8 + ((lane & 15) >> 1)) * a.COUT + o_e0[m];
     const float relu_lo = a.relu ? 0.f : -INFINITY;           // v = max(v, relu_lo): ReLU or identity
     // LDS read offsets of the B fragments: per-lane part (tap of the lane's k group) per k-step; the
     // N-tile part is an immediate
@@ -525,12 +537,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     int ld_left = nt_blk - 1;                                  // advances still allowed (then the walk parks)
     int s_pix0[RD], s_ty0[RD], s_tx0[RD];                      // first pixel / origin of the tile in each ring slot
     int cur_pix0 = 0, cur_ty0 = 0, cur_tx0 = 0;                // ... of the tile in LDS
+    int s_pp0[RD], cur_pp0 = 0;                                // first pooled pixel of the tile (POOL)
 
 #define MMK_RING_LOAD(SLOT)                                                                                  \
     {                                                                                                        \
         const int ty0_ = ld_ty * TH, tx0_ = ld_tx * TW;                                                      \
         const int pix0_ = (ld_b * a.H + ty0_) * a.W + tx0_;                                                  \
         s_pix0[SLOT] = pix0_; s_ty0[SLOT] = ty0_; s_tx0[SLOT] = tx0_;                                        \
+        if constexpr (POOL) s_pp0[SLOT] = (ld_b * Hp + (ty0_ >> 1)) * Wp + (tx0_ >> 1);                      \
         const long org_ = (long)pix0_ - a.W - 1;                       /* halo origin pixel */               \
         const bf16 *base1_ = a.x1 + org_ * a.C1, *base2_ = a.x2 + org_ * a.C2;                               \
         _Pragma("unroll") for (int i = 0; i < RIN; ++i) {                                                    \
@@ -601,6 +615,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
         MMK_RING_SINKS();
     }
     cur_pix0 = s_pix0[0]; cur_ty0 = s_ty0[0]; cur_tx0 = s_tx0[0];
+    if constexpr (POOL) cur_pp0 = s_pp0[0];
     MMK_RING_STORE(0, 0);
     MMK_RING_LOAD(0);
     MMK_RING_SINKS();
@@ -640,7 +655,7 @@ ring_done:;
 #undef MMK_RING_STORE
 }
 
-template <int CK, int CM, int RD, bool EPI>
+template <int CK, int CM, int RD, bool EPI, bool POOL = false>
 int launch_conv_ring(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
@@ -649,10 +664,11 @@ int launch_conv_ring(const ConvArgs &a, hipStream_t st)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     if (per_cu[dev & 63] == 0) {
         if (smem > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_ring_kernel<CK, CM, RD, EPI>,
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int nblk = 0;
-        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_ring_kernel<CK, CM, RD, EPI>, CONV_THREADS, smem));
+        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>, CONV_THREADS,
+                                                                   smem));
         per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
@@ -661,7 +677,8 @@ int launch_conv_ring(const ConvArgs &a, hipStream_t st)
     const int per_xcd = (total + 7) / 8;
     int nb = (32 * per_cu[dev & 63]) / groups;                 // blocks per XCD (32 CUs each)
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    hipLaunchKernelGGL((conv3x3_ring_kernel<CK, CM, RD, EPI>), dim3(8 * nb, groups), dim3(CONV_THREADS), smem, st, a, total, per_xcd);
+    hipLaunchKernelGGL((conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>), dim3(8 * nb, groups), dim3(CONV_THREADS), smem, st, a, total,
+                       per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -674,6 +691,13 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
     // two slots there, and the registers go to occupancy
     constexpr int RDE = 2;
     const bool epi = a.o1.relu_src || a.o1.accumulate || (a.o2.C > 0 && (a.o2.relu_src || a.o2.accumulate));
+    if (a.pool_y != nullptr) {
+        if constexpr (CK == CM && (CK == 16 || CK == 32)) {   // the encoder's second convs below 64 channels
+            if (!epi && a.o2.C == 0) return launch_conv_ring<CK, CM, RD, false, true>(a, st);
+        }
+        mmk::set_error("mmk_conv3x3: pool_y is not supported for this layer (see mmk_conv3x3_pool_fusable)");
+        return MMK_ERR_ARG;
+    }
     return epi ? launch_conv_ring<CK, CM, RDE, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
 }
 
@@ -1041,8 +1065,19 @@ bool use_ring_kernels()
     return v == 1;
 }
 
+// the layers whose producing kernel can write the 2x2 max-pool of its output as well
+bool pool_fusable(int cin, int cout, int B, int H, int W)
+{
+    const bool fits32 = (size_t)B * H * W * (size_t)std::max(cin, cout) < ((size_t)1 << 31);
+    return cin == cout && (cin == 16 || cin == 32) && fits32 && use_ring_kernels() && H >= 2 && W >= 2;
+}
+
 int dispatch_conv(const ConvArgs &a, hipStream_t st)
 {
+    if (a.pool_y != nullptr && !pool_fusable(a.CIN, a.COUT, a.B, a.H, a.W)) {
+        mmk::set_error("mmk_conv3x3: pool_y is not supported for this layer (see mmk_conv3x3_pool_fusable)");
+        return MMK_ERR_ARG;
+    }
     if (conv_is_deep(a.CIN, a.COUT)) return dispatch_conv_deep(a, st);
     const int CK = conv_ck(a.CIN), CM = conv_cm(a.CIN, a.COUT);
     const bool fits32 = (size_t)a.B * a.H * a.W * (size_t)std::max(a.CIN, a.COUT) < ((size_t)1 << 31);
@@ -2538,7 +2573,13 @@ extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
     a.o2 = {(bf16 *)d->y2, (const bf16 *)d->relu_src2, d->O2, d->accumulate2, d->scale2};
     a.B = d->B; a.H = d->H; a.W = d->W; a.CIN = cin; a.COUT = cout;
     a.relu = d->relu; a.drop_p = d->drop_p; a.seed = d->seed;
+    a.pool_y = (bf16 *)d->pool_y;
     return dispatch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t mmk_conv3x3_pool_fusable(int32_t cin, int32_t cout, int32_t B, int32_t H, int32_t W)
+{
+    return pool_fusable(cin, cout, B, H, W) ? 1 : 0;
 }
 
 extern "C" int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,

@@ -55,9 +55,10 @@ def pack_weights_batch(ws, transposed=False):
 
 
 def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0, out=None, out2=None, split=None,
-            relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False):
+            relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False, pool_out=None):
     """3x3 / pad 1 convolution on NHWC bf16.  input = concat(x1, x2); output channels
-    [0,split) -> out, [split,cout) -> out2 (split=None: single output)."""
+    [0,split) -> out, [split,cout) -> out2 (split=None: single output).  ``pool_out`` (B,H//2,W//2,cout):
+    the 2x2 max-pool of the output, written by the same pass (layers for which pool_fusable() holds)."""
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     O1 = cout if split is None else split
@@ -70,9 +71,13 @@ def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0,
                       relu_src1=_p(relu_src), O1=O1, accumulate1=1 if accumulate else 0, scale1=float(scale),
                       y2=_p(out2), relu_src2=_p(relu_src2), O2=O2, accumulate2=1 if accumulate2 else 0,
                       scale2=float(scale2), B=B, H=H, W=W, relu=1 if relu else 0, drop_p=float(drop_p),
-                      seed=int(seed) & 0xFFFFFFFF)
+                      seed=int(seed) & 0xFFFFFFFF, pool_y=_p(pool_out))
     _lib.check(_lib.lib().mmk_conv3x3(ctypes.byref(d), _lib.stream_ptr(x1.device)))
     return (out, out2) if O2 > 0 else out
+
+
+def pool_fusable(cin, cout, B, H, W):
+    return bool(_lib.lib().mmk_conv3x3_pool_fusable(cin, cout, B, H, W))
 
 
 def conv3x3_wgrad(x1, g, cout, x2=None, dWt=None, db=None):
@@ -267,8 +272,14 @@ class _UNet(torch.autograd.Function):
             wa, ba = wb(2 * i)
             wc, bc = wb(2 * i + 1)
             a = conv3x3(t[i - 1], pk(2 * i), ch[i], bias=ba, relu=True)
-            d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed())
-            t.append(maxpool2(d))
+            if pool_fusable(ch[i], ch[i], B, a.shape[1], a.shape[2]):
+                # the second conv writes its 2x2 max-pool as well (no re-read of the full-resolution tensor)
+                pooled = torch.empty(B, a.shape[1] // 2, a.shape[2] // 2, ch[i], dtype=BF16, device=dev)
+                d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed(), pool_out=pooled)
+                t.append(pooled)
+            else:
+                d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed())
+                t.append(maxpool2(d))
             saved["e%d" % i] = (a, d)
         # ---- decoder
         cur = t[5]

@@ -524,3 +524,24 @@ def test_unet_hip_fused_mask_normalisation(B, H, W):
     for (n, _), a, b in zip(model.named_parameters(), [p.grad for p in uh.param_list(model)], want):
         rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
         assert rel < 2e-3, (n, rel)     # bf16 gradient tensors downstream amplify the fp32 summation-order difference
+
+
+@pytest.mark.parametrize("c,B,H,W,drop", [(16, 2, 40, 64, 0.0), (16, 3, 37, 51, 0.1), (32, 2, 24, 96, 0.05), (32, 1, 9, 35, 0.0),
+                                          (16, 9, 160, 160, 0.05), (32, 9, 96, 160, 0.0)])
+def test_conv3x3_fused_maxpool(c, B, H, W, drop):
+    """pool_out: the 2x2 max-pool (floor-rounded, nn.MaxPool2d(2,2)) written by the convolution's own
+    epilogue equals the pooling kernel applied to the stored output, bit for bit — even and odd sizes,
+    images larger than one tile, blocks that walk many tiles."""
+    assert uh.pool_fusable(c, c, B, H, W)
+    x = _rand_nhwc(B, H, W, c, 21)
+    g = torch.Generator().manual_seed(22)
+    w = (torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    wp = uh.pack_weights(w)
+    ref = uh.conv3x3(x, wp, c, bias=b, relu=True, drop_p=drop, seed=7)
+    pooled = torch.full((B, H // 2, W // 2, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = uh.conv3x3(x, wp, c, bias=b, relu=True, drop_p=drop, seed=7, pool_out=pooled)
+    assert torch.equal(out, ref)
+    assert torch.equal(pooled, uh.maxpool2(ref))
+    # layers the fused form does not cover are refused, not silently computed without the pool
+    assert not uh.pool_fusable(64, 64, B, H, W)
