@@ -290,6 +290,12 @@ def test_aux_kernels_vs_torch():
                                                    ctypes.c_void_p(dw3.data_ptr()), ctypes.c_void_p(db3.data_ptr()),
                                                    _lib.stream_ptr(DEV)))
         assert (dw2 - dw3).abs().max().item() < 2e-3 * dw3.abs().max().item() + 1e-3 and torch.allclose(db2, db3)
+    # channel min/max on a plane size that is not a multiple of 4 (scalar loads) and on a large one
+    for shp in [(2, 3, 21, 37), (5, 1, 320, 640)]:
+        xo = (torch.randn(*shp, generator=g) * 3).to(DEV)
+        prm = uh.channel_minmax(xo)
+        mn, mx = xo.amin(dim=(0, 2, 3)), xo.amax(dim=(0, 2, 3))
+        assert torch.equal(prm[:, 0], mn) and torch.equal(prm[:, 1], 1.0 / (mx - mn))
     # max pool fwd / bwd (with the fused relu+dropout factor)
     d = F.relu(torch.randn(2, 16, 12, 20, generator=g)).to(DEV)
     dn = _nhwc(d)
