@@ -150,6 +150,12 @@ int mmk_polar_to_cart(const float *polar, const float *azimuths /*B,A*/,
                       int32_t A, int32_t R, int32_t W, float radar_resolution,
                       int32_t interpolate_crossover, int32_t fix_wobble, float *cart,
                       void *stream);
+/* Two images of one batch resampled with the same azimuths in one pass (FFT and CFAR image of a
+ * scan, icp_weight_dataset.py:350-352): coordinates and tap weights are computed once. */
+int mmk_polar_to_cart_pair(const float *polar, const float *polar2, const float *azimuths,
+                           const float *range_grid, const float *angle_grid, int32_t B, int32_t A,
+                           int32_t R, int32_t W, float radar_resolution, int32_t interpolate_crossover,
+                           int32_t fix_wobble, float *cart, float *cart2, void *stream);
 
 /* weights[b,n] = bilinear(mask[b], point n) with zero padding; fake points
  * (x==0 && y==0) get 0.  cart_resolution / cart_pixel_width as point_to_cart_idx

@@ -116,6 +116,8 @@ def _declare(lib):
         "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,
                                              c_vp, sz, c_vp]),
         "mmk_polar_to_cart": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, f32, i32, i32, c_vp, c_vp]),
+        "mmk_polar_to_cart_pair": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, f32, i32, i32, c_vp, c_vp,
+                                                  c_vp]),
         "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_weight_stats": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restr
                                                             const float *__restrict__ rgrid,
                                                             const float *__restrict__ agrid, int A, int R, int W,
                                                             float res, float half_res, int wrap, int fix_wobble,
-                                                            float *__restrict__ cart)
+                                                            float *__restrict__ cart, const float *__restrict__ polar2,
+                                                            float *__restrict__ cart2)
 {
     extern __shared__ float laz[];
     const int b = blockIdx.y;
@@ -279,6 +280,14 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restr
                       tap_polar(img, A, R, yi + 1, xi, wrap) * (wy * ex) +
                       tap_polar(img, A, R, yi + 1, xi + 1, wrap) * (wy * wx);
     cart[(size_t)b * W * W + pix] = out;
+    // a second image on the same grid (the dataset resamples the FFT and the CFAR image with the same
+    // azimuths, icp_weight_dataset.py:350-352): the coordinates and tap weights are shared
+    if (polar2 != nullptr) {
+        const float *img2 = polar2 + (size_t)b * A * R;
+        cart2[(size_t)b * W * W + pix] =
+            tap_polar(img2, A, R, yi, xi, wrap) * (sy * ex) + tap_polar(img2, A, R, yi, xi + 1, wrap) * (sy * wx) +
+            tap_polar(img2, A, R, yi + 1, xi, wrap) * (wy * ex) + tap_polar(img2, A, R, yi + 1, xi + 1, wrap) * (wy * wx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -535,7 +544,23 @@ extern "C" int mmk_polar_to_cart(const float *polar, const float *azimuths, cons
     const float half_res = (float)((double)radar_resolution / 2.0);
     hipLaunchKernelGGL(polar_to_cart_kernel, dim3(((W + 31) / 32) * ((W + 7) / 8), B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
                        polar, azimuths, range_grid, angle_grid, A, R, W, radar_resolution, half_res,
-                       interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart);
+                       interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart, (const float *)nullptr, (float *)nullptr);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_polar_to_cart_pair(const float *polar, const float *polar2, const float *azimuths, const float *range_grid,
+                                      const float *angle_grid, int32_t B, int32_t A, int32_t R, int32_t W,
+                                      float radar_resolution, int32_t interpolate_crossover, int32_t fix_wobble, float *cart,
+                                      float *cart2, void *stream)
+{
+    MMK_REQUIRE(polar && polar2 && azimuths && range_grid && angle_grid && cart && cart2, "mmk_polar_to_cart_pair: NULL pointer");
+    MMK_REQUIRE(B >= 1 && A >= 2 && R >= 2 && W >= 1, "mmk_polar_to_cart_pair: bad shape");
+    MMK_REQUIRE((size_t)A * 4 <= 64 * 1024, "mmk_polar_to_cart_pair: too many azimuths (%d)", A);
+    const float half_res = (float)((double)radar_resolution / 2.0);
+    hipLaunchKernelGGL(polar_to_cart_kernel, dim3(((W + 31) / 32) * ((W + 7) / 8), B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
+                       polar, azimuths, range_grid, angle_grid, A, R, W, radar_resolution, half_res,
+                       interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart, polar2, cart2);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -223,6 +223,24 @@ def radar_polar_to_cartesian_diff(fft_data, azimuths, radar_resolution, cart_res
     return _back(out, fft_data)
 
 
+def _polar_to_cart_pair(img_a, img_b, azimuths, radar_resolution, cart_pixel_width=640):
+    """radar_polar_to_cartesian_diff of two images that share their azimuths (the FFT and the CFAR
+    image of a scan, icp_weight_dataset.py:350-352) in one launch: same values as two calls."""
+    dev = _hip_device(img_a)
+    a, b = _lib.dev_f32(img_a, dev), _lib.dev_f32(img_b, dev)
+    az = _lib.dev_f32(azimuths, dev)
+    assert a.shape == b.shape
+    B, A, R = a.shape
+    W = int(cart_pixel_width)
+    rg, ag = _device_grids(W, dev)
+    out_a = torch.empty(B, W, W, dtype=torch.float32, device=dev)
+    out_b = torch.empty(B, W, W, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().mmk_polar_to_cart_pair(_lib.ptr(a), _lib.ptr(b), _lib.ptr(az), _lib.ptr(rg), _lib.ptr(ag), B, A, R, W,
+                                                 float(radar_resolution), 1, 1, _lib.ptr(out_a), _lib.ptr(out_b),
+                                                 _lib.stream_ptr(dev)))
+    return _back(out_a, img_a), _back(out_b, img_b)
+
+
 # ----------------------------------------------------------------------------- R9
 class _SampleWeights(torch.autograd.Function):
     """Bilinear gather of the mask at the scan points; backward is the

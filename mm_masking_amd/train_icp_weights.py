@@ -60,8 +60,7 @@ def prepare_batch(raw, params, max_loc_pts=5120, polar_res=0.0596):
     cfar = ru.cfar_mask(fft, polar_res, a_thresh=params["a_thresh"], b_thresh=params["b_thresh"], diff=False)
     pc, _ = ru.extract_pc_padded(cfar, polar_res, az, raw["az_times"], max_loc_pts, diff=False)
     if params.get("network_input_type", "cartesian") == "cartesian":    # icp_weight_dataset.py:350-352
-        fft_img = ru.radar_polar_to_cartesian_diff(fft, az, polar_res)
-        cfar_img = ru.radar_polar_to_cartesian_diff(cfar, az, polar_res)
+        fft_img, cfar_img = ru._polar_to_cart_pair(fft, cfar, az, polar_res)     # one pass, shared coordinates
     else:                                                               # polar network: images stay (400,3360)
         fft_img, cfar_img = fft, cfar
     loc_data = {"raw_pc": pc, "filtered_pc": pc, "fft_data": fft_img, "fft_cfar": cfar_img, "timestamp": 0}

@@ -192,6 +192,17 @@ def test_weight_stats_fused_pass():
     assert (got - mask.grad).abs().max().item() < 1e-6
 
 
+def test_polar_to_cart_pair_equals_two_calls():
+    """The paired resampling used by prepare_batch (FFT + CFAR image, shared coordinates) gives exactly the
+    values of two separate radar_polar_to_cartesian_diff calls."""
+    raw = synthetic.make_batch([0, 1], device=DEV, m_valid=500, m_pad=512)
+    fft, az = raw["fft_polar"], raw["azimuths"]
+    cf = ru.cfar_mask(fft, 0.0596, a_thresh=1.0, b_thresh=0.09, diff=False)
+    a, b = ru._polar_to_cart_pair(fft, cf, az, 0.0596)
+    assert torch.equal(a, ru.radar_polar_to_cartesian_diff(fft, az, 0.0596))
+    assert torch.equal(b, ru.radar_polar_to_cartesian_diff(cf, az, 0.0596))
+
+
 def test_bev_golden_and_point_idx(golden_dir):
     g = _load(golden_dir, "radar_points.npz")
     bev = ru.extract_bev_from_pts(_g(g["bev_pts"])).cpu().numpy()
