@@ -551,3 +551,48 @@ def test_conv3x3_fused_maxpool(c, B, H, W, drop):
     assert torch.equal(pooled, uh.maxpool2(ref))
     # layers the fused form does not cover are refused, not silently computed without the pool
     assert not uh.pool_fusable(64, 64, B, H, W)
+
+
+def test_elementwise_kernels_random_shapes():
+    """Seeded sweep over odd and awkward shapes (tile edges, single rows / columns, non-integer up-sampling
+    ratios) of the kernels around the convolutions, each against its PyTorch expression."""
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(77)
+    for _ in range(10):
+        B = int(rng.integers(1, 4))
+        C = int(rng.choice([8, 16, 32, 64]))
+        hs, ws = int(rng.integers(1, 23)), int(rng.integers(1, 29))
+        ho, wo = hs * 2 + int(rng.integers(0, 2)), ws * 2 + int(rng.integers(0, 2))     # a skip of size 2n or 2n+1
+        # up-sampling forward / adjoint
+        xs = torch.randn(B, C, hs, ws, generator=g).to(DEV)
+        xr = xs.to(torch.bfloat16).float().requires_grad_(True)
+        ur = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=True)
+        u = uh.upsample(_nhwc(xs), ho, wo)
+        assert (u.float() - ur.permute(0, 2, 3, 1)).abs().max().item() < 0.03, (B, C, hs, ws, ho, wo)
+        gu = torch.randn(B, C, ho, wo, generator=g).to(DEV)
+        ur.backward(gu.to(torch.bfloat16).float())
+        gx = uh.upsample_bwd(_nhwc(gu), hs, ws)
+        assert (gx.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 0.05 + 0.008 * xr.grad.abs().max().item(), (B, C, hs, ws)
+        # pooling forward / backward on the up-sampled size
+        if ho >= 2 and wo >= 2:
+            d = F.relu(torch.randn(B, C, ho, wo, generator=g)).to(DEV)
+            dn = _nhwc(d)
+            p = uh.maxpool2(dn)
+            dref = dn.float().permute(0, 3, 1, 2).requires_grad_(True)
+            pref = F.max_pool2d(dref, 2, 2)
+            assert torch.equal(p.float(), pref.permute(0, 2, 3, 1))
+            gy = torch.randn(B, C, ho // 2, wo // 2, generator=g).to(DEV)
+            pref.backward(gy.to(torch.bfloat16).float())
+            gz = uh.maxpool2_bwd(dn, _nhwc(gy), 1.0)
+            assert (gz.float() - (dref.grad * (dref > 0)).permute(0, 2, 3, 1)).abs().max().item() < 0.02
+    # fused pool in the convolution epilogue, random sizes
+    for _ in range(6):
+        c = int(rng.choice([16, 32]))
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 45)), int(rng.integers(2, 70))
+        x = _rand_nhwc(B, H, W, c, int(rng.integers(0, 1000)))
+        w = (torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)).to(DEV)
+        wp = uh.pack_weights(w)
+        ref = uh.conv3x3(x, wp, c, relu=True)
+        pooled = torch.full((B, H // 2, W // 2, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out = uh.conv3x3(x, wp, c, relu=True, pool_out=pooled)
+        assert torch.equal(out, ref) and torch.equal(pooled, uh.maxpool2(ref)), (c, B, H, W)
