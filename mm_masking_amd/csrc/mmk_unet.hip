@@ -429,15 +429,33 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ u32x4 g_zero16;   // zero-initialised, never written
 __device__ u32x4 g_sink16[8]; // write-only: where lanes without an output element store
 
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(v[j] << 16);
+        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8])
+{
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)f[j];
+    return __builtin_bit_cast(u32x4, o);
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CK, int CM, int RD, bool EPI, bool POOL = false>
+template <int CK, int CM, int RD, bool EPI, bool POOL = false, bool C8 = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
     static_assert(!(EPI && POOL), "the pooled output belongs to the forward pass (no epilogue operands)");
+    static_assert(!C8 || (CM == 16 && !POOL), "C8: a single output part of exactly 8 channels");
     constexpr int NS = ksteps(CK);
     constexpr int MT = CM / 16;
     constexpr int NT = 4;
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int NST = MT * NT + (POOL ? MT * 2 : 0);         // stores per stage
+    constexpr int NST = C8 ? 1 : MT * NT + (POOL ? MT * 2 : 0);   // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
     bf16 *w_lds = in_tile + 2 * HT * WT * PK;
@@ -519,6 +537,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int h = 0; h < 2; ++h) p_loff[m][h] = (wv * Wp + h * 8 + ((lane & 15) >> 1)) * a.COUT + o_e0[m];
+    // C8 (exactly 8 output channels): the MFMA layout leaves the four accumulators of a wave half empty
+    // (16-lane groups 2, 3 hold channels 8..15 that do not exist).  v_permlane16_swap + v_permlane32_swap
+    // gather them into one full wave — lane = (n-tile, pixel) with all 8 channels — so that bias / ReLU /
+    // dropout / conversions run once instead of four times and a tile row pair is one 16-byte store (and
+    // one 16-byte load per epilogue operand) per lane.
+    const int n8 = lane >> 4;
+    const int lrow8 = 2 * wv + (n8 >> 1), lcol8 = (n8 & 1) * 16 + (lane & 15);
+    const int lpix8 = lrow8 * a.W + lcol8;
+    const bool c8_has_src = a.o1.relu_src != nullptr, c8_accm = a.o1.accumulate != 0;
+    const float c8_scale = a.o1.scale;
     const float relu_lo = a.relu ? 0.f : -INFINITY;           // v = max(v, relu_lo): ReLU or identity
     // LDS read offsets of the B fragments: per-lane part (tap of the lane's k group) per k-step; the
     // N-tile part is an immediate
@@ -604,6 +632,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
         }
     }
 
+    float bs8[8];
+    if constexpr (C8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            bs8[r] = a.bias ? a.bias[r] : 0.f;
+            asm volatile("" : "+v"(bs8[r]));
+        }
+    }
+
     // Fill the ring.  Sink stores stand in for the epilogues that have not run yet, so that the
     // first stage meets the same load/store queue as every later one:
     //   [tile k+1] NST stores [tile k+2] NST stores ... [tile k+RD] NST stores
@@ -655,7 +692,7 @@ ring_done:;
 #undef MMK_RING_STORE
 }
 
-template <int CK, int CM, int RD, bool EPI, bool POOL = false>
+template <int CK, int CM, int RD, bool EPI, bool POOL = false, bool C8 = false>
 int launch_conv_ring(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
@@ -664,10 +701,10 @@ int launch_conv_ring(const ConvArgs &a, hipStream_t st)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     if (per_cu[dev & 63] == 0) {
         if (smem > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>,
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_ring_kernel<CK, CM, RD, EPI, POOL, C8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int nblk = 0;
-        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>, CONV_THREADS,
+        MMK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_ring_kernel<CK, CM, RD, EPI, POOL, C8>, CONV_THREADS,
                                                                    smem));
         per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
     }
@@ -677,10 +714,20 @@ int launch_conv_ring(const ConvArgs &a, hipStream_t st)
     const int per_xcd = (total + 7) / 8;
     int nb = (32 * per_cu[dev & 63]) / groups;                 // blocks per XCD (32 CUs each)
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    hipLaunchKernelGGL((conv3x3_ring_kernel<CK, CM, RD, EPI, POOL>), dim3(8 * nb, groups), dim3(CONV_THREADS), smem, st, a, total,
+    hipLaunchKernelGGL((conv3x3_ring_kernel<CK, CM, RD, EPI, POOL, C8>), dim3(8 * nb, groups), dim3(CONV_THREADS), smem, st, a, total,
                        per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
+}
+
+inline bool use_c8_epilogue()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_CONV_C8");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
 }
 
 template <int CK, int CM>
@@ -697,6 +744,10 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
         }
         mmk::set_error("mmk_conv3x3: pool_y is not supported for this layer (see mmk_conv3x3_pool_fusable)");
         return MMK_ERR_ARG;
+    }
+    if constexpr (CM == 16) {
+        if (a.COUT == 8 && a.o2.C == 0 && use_c8_epilogue())
+            return epi ? launch_conv_ring<CK, CM, RDE, true, false, true>(a, st) : launch_conv_ring<CK, CM, RD, false, false, true>(a, st);
     }
     return epi ? launch_conv_ring<CK, CM, RDE, true>(a, st) : launch_conv_ring<CK, CM, RD, false>(a, st);
 }
@@ -2090,23 +2141,6 @@ __device__ __forceinline__ void split_granule(int e, int G, int lg, int &pix, in
         gc = e % G;
         pix = e / G;
     }
-}
-
-__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8])
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f[2 * j] = __uint_as_float(v[j] << 16);
-        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
-    }
-}
-
-__device__ __forceinline__ u32x4 pack8(const float (&f)[8])
-{
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)f[j];
-    return __builtin_bit_cast(u32x4, o);
 }
 
 // rh / rw = (n_src - 1) / (n_out - 1), worked out once on the host.  A thread owns one (column, granule)

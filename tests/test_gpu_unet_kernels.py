@@ -596,3 +596,43 @@ def test_elementwise_kernels_random_shapes():
         pooled = torch.full((B, H // 2, W // 2, c), float("nan"), dtype=torch.bfloat16, device=DEV)
         out = uh.conv3x3(x, wp, c, relu=True, pool_out=pooled)
         assert torch.equal(out, ref) and torch.equal(pooled, uh.maxpool2(ref)), (c, B, H, W)
+
+
+_C8_PROBE = r"""
+import hashlib, torch
+from mm_masking_amd import unet_hip as uh
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+def rnd(*shape):
+    return (torch.randn(*shape, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+h = hashlib.sha256()
+for cin, B, H, W in [(8, 2, 37, 83), (16, 3, 64, 96), (32, 1, 21, 40)]:
+    x, src, acc0 = rnd(B, H, W, cin), rnd(B, H, W, 8), rnd(B, H, W, 8)
+    w = (torch.randn(8, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
+    b = torch.randn(8, generator=g).to(dev)
+    wp = uh.pack_weights(w)
+    y1 = uh.conv3x3(x, wp, 8, bias=b, relu=True, drop_p=0.1, seed=11)              # forward role
+    y2 = uh.conv3x3(x, wp, 8, relu_src=src, scale=1.25)                              # data-gradient role
+    y3 = acc0.clone()
+    uh.conv3x3(x, wp, 8, out=y3, accumulate=True, relu_src=src, scale=1.25)         # ... accumulating
+    for y in (y1, y2, y3):
+        h.update(y.cpu().view(torch.int16).numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_conv3x3_eight_channel_epilogue_bit_identical():
+    """The gathered 64-lane epilogue of the 8-output-channel layers (permlane swaps) against the plain
+    one (MMK_CONV_C8=0), in separate processes (the switch is read once): identical bytes for the forward
+    role with dropout, the data-gradient role with a ReLU source, and accumulation."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, MMK_CONV_C8=flag, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _C8_PROBE], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert out[0] == out[1] and len(out[0]) == 64
