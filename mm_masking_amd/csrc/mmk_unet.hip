@@ -465,7 +465,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int NST = C8 ? 1 : MT * NT + (POOL ? MT * 2 : 0);   // stores per stage
+    constexpr int NST = C8 ? 1 : MT * NT + (POOL ? MT : 0);       // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
     bf16 *w_lds = in_tile + 2 * HT * WT * PK;
@@ -529,14 +529,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     for (int n = 0; n < NT; ++n) lane_pix[n] = (2 * wv + (n >> 1)) * a.W + (n & 1) * 16 + (lane & 15);
     // POOL: 2x2 max-pool of the output in the same pass (nn.MaxPool2d(2,2) after the block's second conv,
     // icp_weight_policy.py:122-123).  The wave's two tile rows are one pooling row: the vertical maximum is
-    // between two of its own accumulators, the horizontal one between neighbouring lanes (DPP); even lanes
-    // store 4 channels of pooled pixel (wv, 8 half + lane%16 / 2) of the tile.
+    // between two of its own accumulators, the horizontal one between neighbouring lanes (DPP); lane l stores
+    // 4 channels of pooled pixel (wv, 8 (l & 1) + l%16 / 2) of the tile: even lanes the first 16-pixel half,
+    // odd lanes the second.
     const int Hp = a.H >> 1, Wp = a.W >> 1;
-    int p_loff[MT][2];
+    int p_loff[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) p_loff[m][h] = (wv * Wp + h * 8 + ((lane & 15) >> 1)) * a.COUT + o_e0[m];
+    for (int m = 0; m < MT; ++m) p_loff[m] = (wv * Wp + (lane & 1) * 8 + ((lane & 15) >> 1)) * a.COUT + o_e0[m];
     // C8 (exactly 8 output channels): the MFMA layout leaves the four accumulators of a wave half empty
     // (16-lane groups 2, 3 hold channels 8..15 that do not exist).  v_permlane16_swap + v_permlane32_swap
     // gather them into one full wave — lane = (n-tile, pixel) with all 8 channels — so that bias / ReLU /
