@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 100 /* 0.1.0 */
+#define MMK_VERSION 200 /* 0.2.0 */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -123,6 +123,7 @@ int mmk_nn_profile_end(float *ms_out /*host*/, int32_t max_out, int32_t *n_out /
  * mmk_extract_peaks    <- extract_pc (+mean_peaks_parallel_fast, pol_2_cart)
  *                                                        radar_utils.py:71-106,167-195
  * mmk_polar_to_cart    <- radar_polar_to_cartesian_diff  radar_utils.py:258-336
+ * mmk_cart_to_polar    <- radar_cartesian_to_polar       radar_utils.py:338-372
  * mmk_sample_weights_* <- extract_weights (fwd + autograd bwd) radar_utils.py:108-128
  * mmk_bev_raster       <- extract_bev_from_pts           radar_utils.py:142-165      */
 
@@ -156,6 +157,14 @@ int mmk_polar_to_cart_pair(const float *polar, const float *polar2, const float 
                            const float *range_grid, const float *angle_grid, int32_t B, int32_t A,
                            int32_t R, int32_t W, float radar_resolution, int32_t interpolate_crossover,
                            int32_t fix_wobble, float *cart, float *cart2, void *stream);
+
+/* Cartesian (B,H,W) -> polar (B,A,R) bilinear resample in fp64 <- radar_cartesian_to_polar, radar_utils.py:338-372
+ * (the reference casts its sampling grid to double at :370: fp64 images only).  sin_az / cos_az (B,A) and
+ * range_coords (R) = linspace(0, (R-1) radar_resolution, R) are formed by the host with torch's CPU functions, as the
+ * reference does; the output is bit-identical to the reference's. */
+int mmk_cart_to_polar(const double *cart, const double *sin_az, const double *cos_az, const double *range_coords,
+                      int32_t B, int32_t A, int32_t R, int32_t H, int32_t W, double cart_resolution, double *polar,
+                      void *stream);
 
 /* weights[b,n] = bilinear(mask[b], point n) with zero padding; fake points
  * (x==0 && y==0) get 0.  cart_resolution / cart_pixel_width as point_to_cart_idx
@@ -206,6 +215,10 @@ typedef struct {
     float scale2;
     int32_t B, H, W;
     int32_t relu;          /* forward: ReLU after the bias                                  */
+    float leaky_slope;     /* > 0: the network's LeakyReLU variant (params["leaky"], nn.LeakyReLU(0.1),
+                              icp_weight_policy.py:106): forward max(v, slope v) instead of ReLU; relu_src
+                              epilogues use (src > 0 ? scale : src < 0 or -0.0 ? slope*scale : 0) -- a kept
+                              zero is stored as -0.0, a dropped element as +0.0.  0 = ReLU              */
     float drop_p;          /* forward: inverted dropout with this probability (0 = none)    */
     uint32_t seed;
     void *pool_y;          /* optional bf16 (B,H/2,W/2,O1): nn.MaxPool2d(2,2) of y1 written by the same
@@ -259,7 +272,7 @@ int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int
 int mmk_channel_minmax(const float *x /*B,C,hw*/, int32_t B, int32_t C, int64_t hw, float *part,
                        float *pre /*C*2*/, void *stream);
 int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre,
-                   int32_t B, int32_t H, int32_t Wd, void *y, void *stream);
+                   int32_t B, int32_t H, int32_t Wd, float leaky_slope, void *y, void *stream);
 int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B,
                          int32_t H, int32_t Wd, float *dW, float *db, void *stream);
 
@@ -268,7 +281,7 @@ int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float
  * source (B,H,W,C).                                                                          */
 int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *stream);
 int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
-                     void *gz, void *stream);
+                     float leaky_slope, void *gz, void *stream);
 
 /* nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (icp_weight_policy.py:175-176).
  * _bwd is the adjoint in gather form; relu_src (optional, source-sized) applies
@@ -276,13 +289,13 @@ int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_
 int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo, void *y,
                      void *stream);
 int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo,
-                     const void *relu_src, float scale, void *gx, void *stream);
+                     const void *relu_src, float scale, float leaky_slope, void *gx, void *stream);
 
 /* final_layer: Conv2d(8,1,1x1) + Sigmoid (icp_weight_policy.py:96-99,184): bf16 (npix,8) -> fp32
  * mask (npix).  _bwd: gx = dL/dx * (x > 0 ? scale : 0) (bf16), dW[8] +=, db[1] +=.            */
 int mmk_final_fwd(const void *x, const float *w, const float *bias, int64_t npix, float *mask, void *stream);
 int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
-                  void *gx, float *dW, float *db, void *stream);
+                  float leaky_slope, void *gx, float *dW, float *db, void *stream);
 /* mask_n = mask / amax(mask over the image) per image (icp_weight_policy.py:192-193), amax (B) out;
  * part: B*64 floats of workspace. */
 int mmk_mask_normalize(const float *mask /*B,npix_per*/, int32_t B, int64_t npix_per, float *part,
@@ -292,8 +305,8 @@ int mmk_mask_normalize(const float *mask /*B,npix_per*/, int32_t B, int64_t npix
  * is applied on the fly.  part: B*128 floats, coef: 2*B floats of workspace. */
 int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n,
                              const float *amax, const float *gmask_n, int32_t B, int64_t npix_per,
-                             float scale, float *part, float *coef, void *gx, float *dW, float *db,
-                             void *stream);
+                             float scale, float leaky_slope, float *part, float *coef, void *gx, float *dW,
+                             float *db, void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ class ConvDesc(ctypes.Structure):
                 ("y2", ctypes.c_void_p), ("relu_src2", ctypes.c_void_p), ("O2", ctypes.c_int32),
                 ("accumulate2", ctypes.c_int32), ("scale2", ctypes.c_float),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32),
-                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p)]
+                ("leaky_slope", ctypes.c_float), ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p)]
 
 
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
@@ -100,16 +100,16 @@ def _declare(lib):
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
         "mmk_conv3x3_pool_fusable": (ctypes.c_int32, [i32, i32, i32, i32, i32]),
         "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp]),
-        "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
+        "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
-        "mmk_maxpool2_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, c_vp, c_vp]),
+        "mmk_maxpool2_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, f32, c_vp, c_vp]),
         "mmk_upsample_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, c_vp]),
-        "mmk_upsample_bwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, f32, c_vp, c_vp]),
+        "mmk_upsample_bwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, f32, f32, c_vp, c_vp]),
         "mmk_final_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
-        "mmk_final_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, f32, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_final_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, f32, f32, c_vp, c_vp, c_vp, c_vp]),
         "mmk_mask_normalize": (ctypes.c_int, [c_vp, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
-        "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, c_vp, c_vp,
+        "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, f32, c_vp, c_vp,
                                                     c_vp, c_vp, c_vp, c_vp]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
         "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -118,6 +118,7 @@ def _declare(lib):
         "mmk_polar_to_cart": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, f32, i32, i32, c_vp, c_vp]),
         "mmk_polar_to_cart_pair": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, f32, i32, i32, c_vp, c_vp,
                                                   c_vp]),
+        "mmk_cart_to_polar": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, i32, ctypes.c_double, c_vp, c_vp]),
         "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_weight_stats": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),

@@ -222,6 +222,37 @@ __device__ __forceinline__ float tap_polar(const float *__restrict__ img, int A,
     return img[(size_t)r * R + xi];
 }
 
+// 8f.3 radar_cartesian_to_polar (radar_utils.py:338-372).  One thread per polar cell; fp64 throughout, as
+// the reference (its sampling grid is cast to double at :370, so it only accepts an fp64 image).  sin / cos
+// of the azimuths and the range coordinates come from the host (torch's CPU sin / cos / linspace, the
+// reference's own library calls: device libm results differ in the last bit); every later operation is an
+// IEEE fp64 operation in the reference's order, the four-tap blend the FMA chain of PyTorch's CPU
+// grid_sample kernel (oracle/nn_search.c: mmk_oracle_blend4_f64) -> bit-identical output.
+__global__ __launch_bounds__(256) void cart_to_polar_kernel(const double *__restrict__ cart, const double *__restrict__ sin_az,
+                                                            const double *__restrict__ cos_az, const double *__restrict__ range_coords,
+                                                            int A, int R, int H, int W, double cart_resolution,
+                                                            double *__restrict__ polar)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int a = blockIdx.y, b = blockIdx.z;
+    const double rc = range_coords[r];
+    const double sx = sin_az[(size_t)b * A + a] * rc, sy = cos_az[(size_t)b * A + a] * rc;
+    double u = sx / cart_resolution, v = -sy / cart_resolution;
+    u = u / (double)(W - 1) * 2.0;
+    v = v / (double)(H - 1) * 2.0;
+    const double ix = ((u + 1.0) / 2.0) * (double)(W - 1), iy = ((v + 1.0) / 2.0) * (double)(H - 1);
+    const double x0 = floor(ix), y0 = floor(iy);
+    const double wx = ix - x0, wy = iy - y0, ex = 1.0 - wx, sy1 = 1.0 - wy;
+    const long xi = (long)x0, yi = (long)y0;
+    const double *img = cart + (size_t)b * H * W;
+    auto tap = [&](long y, long x) -> double {
+        return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0;
+    };
+    const double t0 = tap(yi, xi), t1 = tap(yi, xi + 1), t2 = tap(yi + 1, xi), t3 = tap(yi + 1, xi + 1);
+    polar[((size_t)b * A + a) * R + r] = fma(t3, wy * wx, fma(t2, wy * ex, fma(t1, sy1 * wx, t0 * (sy1 * ex))));
+}
+
 // R5 radar_polar_to_cartesian_diff (radar_utils.py:258-336).  One thread per Cartesian
 // pixel; the batch item's azimuth table sits in LDS for the binary search (wobble fix).
 __global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restrict__ polar,
@@ -545,6 +576,19 @@ extern "C" int mmk_polar_to_cart(const float *polar, const float *azimuths, cons
     hipLaunchKernelGGL(polar_to_cart_kernel, dim3(((W + 31) / 32) * ((W + 7) / 8), B), dim3(256), (size_t)A * 4, (hipStream_t)stream,
                        polar, azimuths, range_grid, angle_grid, A, R, W, radar_resolution, half_res,
                        interpolate_crossover ? 1 : 0, fix_wobble ? 1 : 0, cart, (const float *)nullptr, (float *)nullptr);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_cart_to_polar(const double *cart, const double *sin_az, const double *cos_az, const double *range_coords,
+                                 int32_t B, int32_t A, int32_t R, int32_t H, int32_t W, double cart_resolution, double *polar,
+                                 void *stream)
+{
+    MMK_REQUIRE(cart && sin_az && cos_az && range_coords && polar, "mmk_cart_to_polar: NULL pointer");
+    MMK_REQUIRE(B >= 1 && B <= 65535 && A >= 1 && A <= 65535 && R >= 1 && H >= 2 && W >= 2, "mmk_cart_to_polar: bad shape");
+    MMK_REQUIRE(cart_resolution > 0.0, "mmk_cart_to_polar: cart_resolution must be positive");
+    hipLaunchKernelGGL(cart_to_polar_kernel, dim3((R + 255) / 256, A, B), dim3(256), 0, (hipStream_t)stream, cart, sin_az, cos_az,
+                       range_coords, A, R, H, W, cart_resolution, polar);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -161,6 +161,8 @@ struct ConvArgs {
     ConvOutPart o1, o2;    // output channels [0,o1.C) -> o1, [o1.C, o1.C+o2.C) -> o2
     int B, H, W, CIN, COUT;
     int relu;
+    float slope;           // > 0: nn.LeakyReLU(slope) instead of ReLU (forward), and the negative-side factor
+                           // slope * scale of the relu_src epilogues (backward); 0 = plain ReLU
     float drop_p;          // forward dropout on the output (0 = none)
     unsigned seed;
     bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
@@ -200,11 +202,28 @@ __device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const
     sc[3] = ((h2 >> 16) >= d.thr) ? d.inv_keep : 0.f;
 }
 
+// LeakyReLU variant of the network (params["leaky"], icp_weight_policy.py:106: nn.LeakyReLU(0.1)).
+// Forward: max(v, slope v).  The backward factor is recovered from the stored (post-dropout) activation d,
+// as for ReLU:  d > 0 -> scale,  d < 0 -> slope * scale,  dropped -> 0.  A pre-activation of exactly zero
+// that was kept must still count as "negative side" (torch: x > 0 ? g : slope g) and must not look like a
+// dropped element, so a kept zero is stored as -0.0 and a dropped element as +0.0 (the dropout is a select,
+// not a product: -x * 0 would be -0.0).  Nothing downstream distinguishes the two zeros except the factor.
+__device__ __forceinline__ float act_leaky(float v, float slope)
+{
+    const float t = fmaxf(v, v * slope);
+    return (t == 0.f) ? -0.f : t;
+}
+__device__ __forceinline__ float drop_leaky(float v, float sc) { return (sc != 0.f) ? v * sc : 0.f; }
+__device__ __forceinline__ float bwd_factor_leaky(float src, float scale, float slope)
+{
+    return (src > 0.f) ? scale : ((__float_as_uint(src) != 0u) ? scale * slope : 0.f);
+}
+
 // Software-pipelined, persistent convolution: a block walks the stages (tile, input-channel
 // chunk) of its share of the tiles; while the matrix cores work on the stage that sits in
 // LDS, the next stage's halo tile (and weight block, when it changes) is already in flight
 // from HBM/L2 into registers and is written to LDS after the barrier.
-template <int CK, int CM>
+template <int CK, int CM, bool LK = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a, int total_tiles)
 {
     constexpr int NS = ksteps(CK);
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const DropoutParams dp = dropout_params(a.drop_p);
+    constexpr bool lk = LK;                 // LeakyReLU variant of the network (a.slope > 0)
     int chunk = 0;
     load_in(tile, 0);
     load_w(0);
@@ -346,19 +366,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 v[r] = acc[m][n][r] + bs[r];
-                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                                if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
                                 float sc[4];
                                 dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                                for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
                             }
                             bf16 *dst = o_y + p * o_C + cl;
                             if (o_src) {
                                 const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o_src + p * o_C + cl);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f;
+                                for (int r = 0; r < 4; ++r)
+                                    v[r] = lk ? v[r] * bwd_factor_leaky((float)sv[r], o_scale, a.slope)
+                                              : (((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f);
                             }
                             if (o_acc) {
                                 const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
@@ -383,7 +405,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_kernel(const ConvArgs a,
     }
 }
 
-template <int CK, int CM>
+template <int CK, int CM, bool LK = false>
 int launch_conv(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
@@ -392,7 +414,7 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
         int dev = 0;
         MMK_CHECK_HIP(hipGetDevice(&dev));
         if (!attr_set[dev & 63]) {
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_kernel<CK, CM, LK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             attr_set[dev & 63] = true;
         }
     }
@@ -404,7 +426,7 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
     const int total = tiles * a.B;
     int gx = (256 * per_cu) / groups;
     gx = gx < 1 ? 1 : (gx > total ? total : gx);
-    hipLaunchKernelGGL((conv3x3_kernel<CK, CM>), dim3(gx, groups), dim3(CONV_THREADS), smem, st, a, total);
+    hipLaunchKernelGGL((conv3x3_kernel<CK, CM, LK>), dim3(gx, groups), dim3(CONV_THREADS), smem, st, a, total);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -776,7 +798,7 @@ struct DeepCfg {
     static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16);
 };
 
-template <int BM, int NT>
+template <int BM, int NT, bool LK = false>
 __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
     using C = DeepCfg<BM, NT>;
@@ -853,6 +875,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     reset_acc();
 
     const DropoutParams dp = dropout_params(a.drop_p);
+    constexpr bool lk = LK;                 // LeakyReLU variant of the network (a.slope > 0)
     // fragment addresses that do not depend on the stage
     const bf16 *b_base = in_tile + ((size_t)(wn * WT + (lane & 15))) * PK + 8 * (lane >> 4);
     const bf16 *a_base = w_lds + ((size_t)(wm * MT) * 64 + lane) * 8;
@@ -975,19 +998,21 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 v[r] = acc[m][n][r];
-                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                                if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
                                 float sc[4];
                                 const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
                                 dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                                for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
                             }
                             if (m_has_src[m]) {
                                 const bf16x4 sv = __builtin_bit_cast(bf16x4, (unsigned long long)slo[m] | ((unsigned long long)shi[m] << 32));
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * m_scale[m] : 0.f;
+                                for (int r = 0; r < 4; ++r)
+                                    v[r] = lk ? v[r] * bwd_factor_leaky((float)sv[r], m_scale[m], a.slope)
+                                              : (((float)sv[r] > 0.f) ? v[r] * m_scale[m] : 0.f);
                             }
                             if (any_acc) {
                                 const bf16x4 ov = __builtin_bit_cast(bf16x4, (unsigned long long)alo[m] | ((unsigned long long)ahi[m] << 32));
@@ -1033,19 +1058,21 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 v[r] = acc[m][n][r];
-                                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                                if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
                                 float sc[4];
                                 dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                                for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
                             }
                             bf16 *dst = o_y + p * o_C + cl;
                             if (o_src) {
                                 const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o_src + p * o_C + cl);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = ((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f;
+                                for (int r = 0; r < 4; ++r)
+                                    v[r] = lk ? v[r] * bwd_factor_leaky((float)sv[r], o_scale, a.slope)
+                                              : (((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f);
                             }
                             if (o_acc) {
                                 const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
@@ -1070,7 +1097,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     }
 }
 
-template <int BM, int NT>
+template <int BM, int NT, bool LK = false>
 int launch_conv_deep(const ConvArgs &a, hipStream_t st)
 {
     using C = DeepCfg<BM, NT>;
@@ -1079,7 +1106,7 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
         if (C::SMEM > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT, LK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)C::SMEM));
         attr_set[dev & 63] = true;
     }
@@ -1089,7 +1116,7 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     const int per_xcd = (total + 7) / 8;
     int nb = 32 / groups;                                    // one 8-wave block per CU, 32 CUs per XCD
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
+    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -1098,6 +1125,11 @@ int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
 {
     const int BM = conv_cm(a.CIN, a.COUT);
     const bool narrow = a.W <= 48;          // NT = 3 (48-pixel tile rows) wastes less than NT = 5 there
+    if (a.slope > 0.f) {
+#define MMK_DEEP_CASE(M) if (BM == M) return narrow ? launch_conv_deep<M, 3, true>(a, st) : launch_conv_deep<M, 5, true>(a, st)
+        MMK_DEEP_CASE(16); MMK_DEEP_CASE(32); MMK_DEEP_CASE(64); MMK_DEEP_CASE(128);
+#undef MMK_DEEP_CASE
+    }
 #define MMK_DEEP_CASE(M) if (BM == M) return narrow ? launch_conv_deep<M, 3>(a, st) : launch_conv_deep<M, 5>(a, st)
     MMK_DEEP_CASE(16); MMK_DEEP_CASE(32); MMK_DEEP_CASE(64); MMK_DEEP_CASE(128);
 #undef MMK_DEEP_CASE
@@ -1124,13 +1156,22 @@ bool pool_fusable(int cin, int cout, int B, int H, int W)
 
 int dispatch_conv(const ConvArgs &a, hipStream_t st)
 {
-    if (a.pool_y != nullptr && !pool_fusable(a.CIN, a.COUT, a.B, a.H, a.W)) {
+    if (a.pool_y != nullptr && (a.slope > 0.f || !pool_fusable(a.CIN, a.COUT, a.B, a.H, a.W))) {
         mmk::set_error("mmk_conv3x3: pool_y is not supported for this layer (see mmk_conv3x3_pool_fusable)");
         return MMK_ERR_ARG;
     }
     if (conv_is_deep(a.CIN, a.COUT)) return dispatch_conv_deep(a, st);
     const int CK = conv_ck(a.CIN), CM = conv_cm(a.CIN, a.COUT);
     const bool fits32 = (size_t)a.B * a.H * a.W * (size_t)std::max(a.CIN, a.COUT) < ((size_t)1 << 31);
+    // (the LeakyReLU variant of the network runs the thin layers on the plain pipelined kernel: the ring
+    // kernel's straight-line epilogue is tuned for the reference's default configuration)
+    if (a.slope > 0.f) {
+#define MMK_CONV_CASE(K, M) if (CK == K && CM == M) return launch_conv<K, M, true>(a, st)
+        MMK_CONV_CASE(8, 16); MMK_CONV_CASE(8, 32); MMK_CONV_CASE(8, 64);
+        MMK_CONV_CASE(16, 16); MMK_CONV_CASE(16, 32); MMK_CONV_CASE(16, 64);
+        MMK_CONV_CASE(32, 16); MMK_CONV_CASE(32, 32);
+#undef MMK_CONV_CASE
+    }
     if (a.CIN == CK && CM <= 32 && fits32 && use_ring_kernels()) {
 #define MMK_RING_CASE(K, M) if (CK == K && CM == M) return launch_conv_ring_epi<K, M>(a, st)
         MMK_RING_CASE(8, 16); MMK_RING_CASE(8, 32); MMK_RING_CASE(16, 16); MMK_RING_CASE(16, 32);
@@ -1820,7 +1861,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
 // padding is of the normalised image.
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
                                                          const float *__restrict__ bias, const float *__restrict__ pre, int B, int H,
-                                                         int W, bf16 *__restrict__ y)
+                                                         int W, float slope, bf16 *__restrict__ y)
 {
     __shared__ float ws[8 * 4 * 9 + 8];
     for (int i = threadIdx.x; i < 8 * CIN * 9; i += blockDim.x) ws[i] = Wt[i];
@@ -1848,7 +1889,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
         }
         bf16x8 o;
 #pragma unroll
-        for (int co = 0; co < 8; ++co) o[co] = (bf16)fmaxf(acc[co], 0.f);
+        for (int co = 0; co < 8; ++co) o[co] = (bf16)((slope > 0.f) ? act_leaky(acc[co], slope) : fmaxf(acc[co], 0.f));
         *reinterpret_cast<bf16x8 *>(y + p * 8) = o;
     }
 }
@@ -1927,7 +1968,7 @@ __device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, 
 
 __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
                                                             const float *__restrict__ bias, const float *__restrict__ pre, int B,
-                                                            int H, int W, bf16 *__restrict__ y)
+                                                            int H, int W, float slope, bf16 *__restrict__ y)
 {
     // (weights and bias are read at wave-uniform addresses: scalar loads, operands straight from SGPRs)
     float bs[8];
@@ -1967,7 +2008,7 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
         for (int px = 0; px < 4; ++px) {
             bf16x8 o;
 #pragma unroll
-            for (int co = 0; co < 8; ++co) o[co] = (bf16)fmaxf(acc[px][co], 0.f);
+            for (int co = 0; co < 8; ++co) o[co] = (bf16)((slope > 0.f) ? act_leaky(acc[px][co], slope) : fmaxf(acc[px][co], 0.f));
             *reinterpret_cast<bf16x8 *>(dst + px * 8) = o;
         }
     }
@@ -2075,7 +2116,7 @@ __global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, in
 // Backward of dropout(relu(.)) -> maxpool in one pass: the pooled gradient goes to the first
 // maximal position (scan order, as torch does) times (d > 0 ? scale : 0).
 __global__ void maxpool2_bwd_kernel(const bf16 *__restrict__ d, const bf16 *__restrict__ gy, int B, int H, int W, int C,
-                                    float scale, bf16 *__restrict__ gz)
+                                    float scale, float slope, bf16 *__restrict__ gz)
 {
     const int Ho = H / 2, Wo = W / 2, G = C / 8;
     const size_t n = (size_t)B * Ho * Wo * G;
@@ -2098,7 +2139,7 @@ __global__ void maxpool2_bwd_kernel(const bf16 *__restrict__ d, const bf16 *__re
 #pragma unroll
         for (int k = 1; k < 4; ++k)
             if ((float)v[k][j] > m) { m = (float)v[k][j]; arg = k; }
-        const float gv = (m > 0.f) ? (float)g[j] * scale : 0.f;
+        const float gv = (slope > 0.f) ? (float)g[j] * bwd_factor_leaky(m, scale, slope) : ((m > 0.f) ? (float)g[j] * scale : 0.f);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k][j] = (bf16)((k == arg) ? gv : 0.f);
     }
@@ -2218,7 +2259,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const bf16 *__restric
 template <bool POW2>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16 *__restrict__ gy, int Hs, int Ws, int C, int Ho, int Wo,
                                                            float rh, float rw, int lg, const bf16 *__restrict__ relu_src,
-                                                           float scale, bf16 *__restrict__ gx)
+                                                           float scale, float slope, bf16 *__restrict__ gx)
 {
     // grid: x = (source pixel, granule) of one source row, y = group of UP_ROWS source rows, z = image
     constexpr int MAXW = 8, NW = 5, R = UP_ROWS;
@@ -2317,7 +2358,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16 *__restric
             float sv[8];
             unpack8(*reinterpret_cast<const u32x4 *>(relu_src + po), sv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r][j] = (sv[j] > 0.f) ? acc[r][j] * scale : 0.f;
+            for (int j = 0; j < 8; ++j)
+                acc[r][j] = (slope > 0.f) ? acc[r][j] * bwd_factor_leaky(sv[j], scale, slope) : ((sv[j] > 0.f) ? acc[r][j] * scale : 0.f);
         }
         *reinterpret_cast<u32x4 *>(gx + po) = pack8(acc[r]);
     }
@@ -2342,7 +2384,7 @@ __global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__rest
 // g * (1 / a) + (m == a ? t : 0)  with a = amax, t = -(sum g m_n) / a / count(m == a).
 __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ mask, const float *__restrict__ gmask,
-                                                        size_t npix_per, const float *__restrict__ coef, float scale,
+                                                        size_t npix_per, const float *__restrict__ coef, float scale, float slope,
                                                         bf16 *__restrict__ gx, float *__restrict__ dW, float *__restrict__ db)
 {
     __shared__ float red[4][9];
@@ -2364,7 +2406,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xv = (float)v[j];
-            o[j] = (bf16)((xv > 0.f) ? gl * wv8[j] * scale : 0.f);
+            o[j] = (bf16)((slope > 0.f) ? gl * wv8[j] * bwd_factor_leaky(xv, scale, slope) : ((xv > 0.f) ? gl * wv8[j] * scale : 0.f));
             acc[j] += gl * xv;
         }
         acc[8] += gl;
@@ -2605,7 +2647,8 @@ extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
     a.o1 = {(bf16 *)d->y1, (const bf16 *)d->relu_src1, d->O1, d->accumulate1, d->scale1};
     a.o2 = {(bf16 *)d->y2, (const bf16 *)d->relu_src2, d->O2, d->accumulate2, d->scale2};
     a.B = d->B; a.H = d->H; a.W = d->W; a.CIN = cin; a.COUT = cout;
-    a.relu = d->relu; a.drop_p = d->drop_p; a.seed = d->seed;
+    MMK_REQUIRE(d->leaky_slope >= 0.f && d->leaky_slope < 1.f, "mmk_conv3x3: leaky_slope must be in [0, 1)");
+    a.relu = d->relu; a.slope = d->leaky_slope; a.drop_p = d->drop_p; a.seed = d->seed;
     a.pool_y = (bf16 *)d->pool_y;
     return dispatch_conv(a, (hipStream_t)stream);
 }
@@ -2700,20 +2743,22 @@ extern "C" int mmk_channel_minmax(const float *x, int32_t B, int32_t C, int64_t 
 }
 
 extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre, int32_t B,
-                              int32_t H, int32_t Wd, void *y, void *stream)
+                              int32_t H, int32_t Wd, float leaky_slope, void *y, void *stream)
 {
     MMK_REQUIRE(x && W && y, "mmk_conv_first: NULL pointer");
+    MMK_REQUIRE(leaky_slope >= 0.f && leaky_slope < 1.f, "mmk_conv_first: leaky_slope must be in [0, 1)");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first: bad shape (cin must be 1..4)");
     const size_t npix = (size_t)B * H * Wd;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
         const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 4096);
         hipLaunchKernelGGL(conv_first_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd,
-                           (bf16 *)y);
+                           leaky_slope, (bf16 *)y);
         MMK_LAUNCH_CHECK();
         return MMK_OK;
     }
     const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 8192);
-    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd, (bf16 *)y);
+    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd, leaky_slope,
+                       (bf16 *)y);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2749,12 +2794,12 @@ extern "C" int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, 
 }
 
 extern "C" int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
-                                void *gz, void *stream)
+                                float leaky_slope, void *gz, void *stream)
 {
     MMK_REQUIRE(d && gy && gz && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_bwd: bad argument");
     const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)d,
-                       (const bf16 *)gy, B, H, W, C, scale, (bf16 *)gz);
+                       (const bf16 *)gy, B, H, W, C, scale, leaky_slope, (bf16 *)gz);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2795,7 +2840,7 @@ extern "C" int mmk_upsample_fwd(const void *x, int32_t B, int32_t Hs, int32_t Ws
 }
 
 extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ho, int32_t Wo,
-                                const void *relu_src, float scale, void *gx, void *stream)
+                                const void *relu_src, float scale, float leaky_slope, void *gx, void *stream)
 {
     MMK_REQUIRE(gy && gx && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1 && C % 8 == 0, "mmk_upsample_bwd: bad argument");
     MMK_REQUIRE(Hs <= 65535 && B <= 65535, "mmk_upsample_bwd: shape exceeds the launch grid");
@@ -2803,10 +2848,10 @@ extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t W
     const dim3 grid(nblk((size_t)Ws * (C / 8), 256), (Hs + UP_ROWS - 1) / UP_ROWS, B);
     if (ug.lg >= 0)
         hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
-                           ug.rh, ug.rw, ug.lg, (const bf16 *)relu_src, scale, (bf16 *)gx);
+                           ug.rh, ug.rw, ug.lg, (const bf16 *)relu_src, scale, leaky_slope, (bf16 *)gx);
     else
         hipLaunchKernelGGL(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
-                           ug.rh, ug.rw, 0, (const bf16 *)relu_src, scale, (bf16 *)gx);
+                           ug.rh, ug.rw, 0, (const bf16 *)relu_src, scale, leaky_slope, (bf16 *)gx);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2821,12 +2866,12 @@ extern "C" int mmk_final_fwd(const void *x, const float *w, const float *bias, i
 }
 
 extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
-                             void *gx, float *dW, float *db, void *stream)
+                             float leaky_slope, void *gx, float *dW, float *db, void *stream)
 {
     MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && npix >= 1, "mmk_final_bwd: bad argument");
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);   // 9 same-address atomics per block
     hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
-                       (size_t)npix, (const float *)nullptr, scale, (bf16 *)gx, dW, db);
+                       (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -2845,8 +2890,8 @@ extern "C" int mmk_mask_normalize(const float *mask, int32_t B, int64_t npix_per
 }
 
 extern "C" int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n, const float *amax,
-                                        const float *gmask_n, int32_t B, int64_t npix_per, float scale, float *part, float *coef,
-                                        void *gx, float *dW, float *db, void *stream)
+                                        const float *gmask_n, int32_t B, int64_t npix_per, float scale, float leaky_slope,
+                                        float *part, float *coef, void *gx, float *dW, float *db, void *stream)
 {
     MMK_REQUIRE(x && w && mask && mask_n && amax && gmask_n && part && coef && gx && dW && db, "mmk_final_bwd_normalized: NULL pointer");
     MMK_REQUIRE(B >= 1 && B <= 65535 && npix_per >= 1, "mmk_final_bwd_normalized: bad shape");
@@ -2858,7 +2903,7 @@ extern "C" int mmk_final_bwd_normalized(const void *x, const float *w, const flo
     // ~512 blocks in all (9 same-address atomics per block)
     const unsigned per = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)npix_per + 255) / 256, (512 + B - 1) / B));
     hipLaunchKernelGGL(final_bwd_kernel, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
-                       scale, (bf16 *)gx, dW, db);
+                       scale, leaky_slope, (bf16 *)gx, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -3,9 +3,12 @@
 ``forward``/``icp`` signatures and return values, same ``state_dict`` keys), with
 
   * the mask U-Net in hand-written NHWC bf16 MFMA kernels (unet_hip.py ->
-    csrc/mmk_unet.hip) for the reference's default configuration (ReLU, no batch
-    norm; Cartesian or polar input of any size >= 32 x 32); the leaky-ReLU /
-    batch-norm variants run the same ``nn.Module`` tree on PyTorch-ROCm (MIOpen),
+    csrc/mmk_unet.hip): ReLU (the reference's default) and LeakyReLU(0.1)
+    (``params["leaky"]``) networks, Cartesian or polar input of any size >= 32 x 32.
+    There is no vendor-library (MIOpen) or CPU fallback on a HIP device; the
+    ``nn.Module`` tree is the parameter store (identical ``state_dict``) and, with the
+    explicit ``unet_backend="torch"`` on a CPU device, the host-logic mirror the CPU
+    tests compare with the reference's golden vectors,
   * ``extract_weights`` and the differentiable ICP in hand-written HIP kernels
     (radar_utils.py / dICP/ICP.py of this package -> libmmk_hip.so).
 
@@ -76,12 +79,11 @@ class LearnICPWeightPolicy(nn.Module):
         self.icp_loss_fn = params.get("icp_loss_fn", {"name": "cauchy", "metric": 1.0})
         self.icp_trim_dist = params.get("icp_trim_dist", 5.0)
         self.icp_dim = params.get("icp_dim", 2)
-        # conv compute dtype: bf16 MFMA through MIOpen on a HIP device, fp32 masters
-        self.amp_dtype = params.get("amp_dtype", torch.bfloat16)
-        self.channels_last = params.get("channels_last", True)
-        # "hip": hand-written NHWC bf16 kernels (csrc/mmk_unet.hip) for the reference's default
-        # network configuration; "torch": nn.Conv2d on MIOpen (leaky ReLU / batch norm variants)
+        # "hip" (the product path): hand-written NHWC bf16 kernels (csrc/mmk_unet.hip), fp32 masters;
+        # "torch": the nn.Module tree evaluated by PyTorch on the CPU -- host-logic mirror for tests only
         self.unet_backend = params.get("unet_backend", "hip")
+        if self.unet_backend not in ("hip", "torch"):
+            raise ValueError("unet_backend must be 'hip' or 'torch' (got %r)" % (self.unet_backend,))
         self._step = 0
 
         self.mean_num_pts = 0.0
@@ -149,23 +151,20 @@ class LearnICPWeightPolicy(nn.Module):
         return torch.stack(chans, dim=1)
 
     def _unet(self, input_data):
-        use_amp = input_data.is_cuda and self.amp_dtype is not None and self.amp_dtype != torch.float32
-        if self.channels_last and input_data.is_cuda:
-            input_data = input_data.contiguous(memory_format=torch.channels_last)
-        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=use_amp):
-            enc_layers = []
-            for layer in self.encoder:
-                enc_layers.append(input_data)
-                input_data = layer(input_data)
-            enc_layers.reverse()
-            for i, decoder_layer in enumerate(self.decoder):
-                skip_con = enc_layers[i]
-                input_data = nn.functional.interpolate(input_data, size=(skip_con.shape[2], skip_con.shape[3]),
-                                                       mode="bilinear", align_corners=True)
-                input_data = decoder_layer(input_data)
-                input_data = torch.cat([skip_con, input_data.to(skip_con.dtype)], dim=1)
-                input_data = decoder_layer(input_data)   # same weights applied twice (:178,182)
-            logits = self.final_layer[0](input_data)
+        """icp_weight_policy.py:161-184 through the nn.Module tree (fp32, CPU: tests only)."""
+        enc_layers = []
+        for layer in self.encoder:
+            enc_layers.append(input_data)
+            input_data = layer(input_data)
+        enc_layers.reverse()
+        for i, decoder_layer in enumerate(self.decoder):
+            skip_con = enc_layers[i]
+            input_data = nn.functional.interpolate(input_data, size=(skip_con.shape[2], skip_con.shape[3]),
+                                                   mode="bilinear", align_corners=True)
+            input_data = decoder_layer(input_data)
+            input_data = torch.cat([skip_con, input_data], dim=1)
+            input_data = decoder_layer(input_data)   # same weights applied twice (:178,182)
+        logits = self.final_layer[0](input_data)
         return torch.sigmoid(logits.float()).squeeze(1)
 
     def forward(self, batch_scan, batch_map, T_init, binary=False, override_mask=None, neptune_run=None, epoch=0,
@@ -177,12 +176,20 @@ class LearnICPWeightPolicy(nn.Module):
 
         if override_mask is None:
             raw_in = self._network_input(fft_data, fft_cfar, normalize=False)
-            # any image of at least 32 x 32 (five floor-rounding poolings leave >= 1 pixel): the Cartesian
-            # 640 x 640 grid and the polar 400 x 3360 one (network_input_type "polar") alike
-            use_hip = (self.unet_backend == "hip" and raw_in.is_cuda and not self.leaky and not self.batch_norm
-                       and raw_in.shape[1] <= 4 and raw_in.shape[2] >= 32 and raw_in.shape[3] >= 32)
-            if use_hip:
-                from . import unet_hip
+            if self.unet_backend == "hip":
+                from . import _lib, unet_hip
+                if not raw_in.is_cuda:
+                    raise _lib.MmkError("the mask U-Net is a set of HIP kernels with no CPU path: params['device'] must be "
+                                        "a HIP device (unet_backend='torch' is the CPU host-logic mirror used by tests)")
+                if self.batch_norm:
+                    raise NotImplementedError("params['batch_norm']=True is not implemented by the hand-written U-Net "
+                                              "(the reference's default is False, train_icp_weights.py:381); there is "
+                                              "no vendor-library fallback")
+                # any image of at least 32 x 32 (five floor-rounding poolings leave >= 1 pixel): the Cartesian
+                # 640 x 640 grid and the polar 400 x 3360 one (network_input_type "polar") alike
+                if raw_in.shape[1] > 4 or raw_in.shape[2] < 32 or raw_in.shape[3] < 32:
+                    raise _lib.MmkError("mask U-Net: unsupported network input %s (1..4 channels, at least 32 x 32)"
+                                        % (tuple(raw_in.shape),))
                 self._step += 1
                 if "minmax" in self.normalize_type:
                     # min-max normalisation folded into the first layer's loads: one min/max pass, no
@@ -192,9 +199,14 @@ class LearnICPWeightPolicy(nn.Module):
                 else:
                     net_in, pre = self._normalize_channels(raw_in), None
                 # (the amax normalisation below rides inside the same autograd node)
-                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre)
+                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre,
+                                                 slope=0.1 if self.leaky else 0.0)
                 normalised = self.norm_weights
             else:
+                if raw_in.is_cuda:
+                    from . import _lib
+                    raise _lib.MmkError("unet_backend='torch' is the CPU host-logic mirror (tests only); on a HIP device "
+                                        "the U-Net runs on the hand-written kernels (unet_backend='hip')")
                 weight_mask = self._unet(self._normalize_channels(raw_in))
                 normalised = False
         else:

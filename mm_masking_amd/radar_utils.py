@@ -138,9 +138,30 @@ def radar_polar_to_cartesian(*args, **kwargs):
                               "use radar_polar_to_cartesian_diff")
 
 
-def radar_cartesian_to_polar(*args, **kwargs):
-    """radar_utils.py:338-372.  Never called upstream: outside the hot-path scope."""
-    raise NotImplementedError("radar_cartesian_to_polar is unused upstream and out of scope")
+def radar_cartesian_to_polar(cart, azimuths, radar_resolution, cart_resolution=0.2384, polar_pixel_shape=(400, 3360)):
+    """radar_utils.py:338-372.  (B,H,W) fp64 + (B,A) -> (B,A,R) fp64, bit-identical to the reference.
+    As upstream, only an fp64 image is accepted: the reference casts its sampling grid to double (:370)
+    and ``F.grid_sample`` raises ``RuntimeError`` on the dtype mismatch for anything else — same error here.
+    sin / cos of the azimuths and the range coordinates are formed on the host with the reference's own
+    torch CPU calls (B*A + R numbers); products, divisions and the bilinear gather run in the HIP kernel."""
+    if cart.dtype != torch.float64:
+        raise RuntimeError("expected scalar type Float but found Double" if cart.dtype == torch.float32 else
+                           "expected scalar type %s but found Double" % str(cart.dtype).replace("torch.", "").capitalize())
+    dev = _hip_device(cart)
+    x = cart.detach().to(dev).contiguous()
+    B, H, W = x.shape
+    A, R = int(polar_pixel_shape[0]), int(polar_pixel_shape[1])
+    if azimuths.shape != (B, A):
+        raise ValueError("azimuths must be (B, %d) (got %s)" % (A, tuple(azimuths.shape)))
+    az = azimuths.detach().to(device="cpu", dtype=torch.float64)
+    rc = form_polar_range_grid(polar_resolution=radar_resolution, polar_pixel_shape=polar_pixel_shape, dtype=torch.float64,
+                               device="cpu")[0]
+    s_az, c_az = torch.sin(az).to(dev).contiguous(), torch.cos(az).to(dev).contiguous()
+    rc = rc.contiguous().to(dev)
+    out = torch.empty(B, A, R, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().mmk_cart_to_polar(_lib.ptr(x), _lib.ptr(s_az), _lib.ptr(c_az), _lib.ptr(rc), B, A, R, H, W,
+                                            float(cart_resolution), _lib.ptr(out), _lib.stream_ptr(dev)))
+    return _back(out, cart)
 
 
 # ----------------------------------------------------------------------------- R2

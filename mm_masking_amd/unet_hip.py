@@ -55,10 +55,12 @@ def pack_weights_batch(ws, transposed=False):
 
 
 def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0, out=None, out2=None, split=None,
-            relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False, pool_out=None):
+            relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False, pool_out=None,
+            slope=0.0):
     """3x3 / pad 1 convolution on NHWC bf16.  input = concat(x1, x2); output channels
     [0,split) -> out, [split,cout) -> out2 (split=None: single output).  ``pool_out`` (B,H//2,W//2,cout):
-    the 2x2 max-pool of the output, written by the same pass (layers for which pool_fusable() holds)."""
+    the 2x2 max-pool of the output, written by the same pass (layers for which pool_fusable() holds).
+    ``slope`` > 0: the LeakyReLU variant (forward activation and the relu_src factors, see include/mmk.h)."""
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     O1 = cout if split is None else split
@@ -70,7 +72,8 @@ def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0,
     d = _lib.ConvDesc(x1=_p(x1), x2=_p(x2), C1=C1, C2=C2, wpack=_p(wpack), bias=_p(bias), y1=_p(out),
                       relu_src1=_p(relu_src), O1=O1, accumulate1=1 if accumulate else 0, scale1=float(scale),
                       y2=_p(out2), relu_src2=_p(relu_src2), O2=O2, accumulate2=1 if accumulate2 else 0,
-                      scale2=float(scale2), B=B, H=H, W=W, relu=1 if relu else 0, drop_p=float(drop_p),
+                      scale2=float(scale2), B=B, H=H, W=W, relu=1 if relu else 0, leaky_slope=float(slope),
+                      drop_p=float(drop_p),
                       seed=int(seed) & 0xFFFFFFFF, pool_y=_p(pool_out))
     _lib.check(_lib.lib().mmk_conv3x3(ctypes.byref(d), _lib.stream_ptr(x1.device)))
     return (out, out2) if O2 > 0 else out
@@ -163,12 +166,12 @@ def _sp(dev):
     return _lib.stream_ptr(dev)
 
 
-def conv_first(x, w, b, pre=None):
+def conv_first(x, w, b, pre=None, slope=0.0):
     """x fp32 (B,cin,H,W) -> bf16 (B,H,W,8), + bias + ReLU (encoder.0.0).  ``pre`` (cin,2): per-channel
     (offset, reciprocal scale) applied to x while loading (see channel_minmax)."""
     B, cin, H, W = x.shape
     y = torch.empty(B, H, W, 8, dtype=BF16, device=x.device)
-    _lib.check(_lib.lib().mmk_conv_first(_p(x), cin, _p(w), _p(b), _p(pre), B, H, W, _p(y), _sp(x.device)))
+    _lib.check(_lib.lib().mmk_conv_first(_p(x), cin, _p(w), _p(b), _p(pre), B, H, W, float(slope), _p(y), _sp(x.device)))
     return y
 
 
@@ -189,10 +192,10 @@ def maxpool2(x):
     return y
 
 
-def maxpool2_bwd(d, gy, scale):
+def maxpool2_bwd(d, gy, scale, slope=0.0):
     B, H, W, C = d.shape
     gz = torch.empty_like(d)
-    _lib.check(_lib.lib().mmk_maxpool2_bwd(_p(d), _p(gy), B, H, W, C, float(scale), _p(gz), _sp(d.device)))
+    _lib.check(_lib.lib().mmk_maxpool2_bwd(_p(d), _p(gy), B, H, W, C, float(scale), float(slope), _p(gz), _sp(d.device)))
     return gz
 
 
@@ -203,11 +206,11 @@ def upsample(x, Ho, Wo):
     return y
 
 
-def upsample_bwd(gy, Hs, Ws, relu_src=None, scale=1.0):
+def upsample_bwd(gy, Hs, Ws, relu_src=None, scale=1.0, slope=0.0):
     B, Ho, Wo, C = gy.shape
     gx = torch.empty(B, Hs, Ws, C, dtype=BF16, device=gy.device)
-    _lib.check(_lib.lib().mmk_upsample_bwd(_p(gy), B, Hs, Ws, C, Ho, Wo, _p(relu_src), float(scale), _p(gx),
-                                           _sp(gy.device)))
+    _lib.check(_lib.lib().mmk_upsample_bwd(_p(gy), B, Hs, Ws, C, Ho, Wo, _p(relu_src), float(scale), float(slope),
+                                           _p(gx), _sp(gy.device)))
     return gx
 
 
@@ -238,7 +241,7 @@ class _UNet(torch.autograd.Function):
     backward is the hand-scheduled reverse pass (no autograd graph inside)."""
 
     @staticmethod
-    def forward(ctx, x, pre, drop_p, seed, training, norm, *params):
+    def forward(ctx, x, pre, drop_p, seed, training, norm, slope, *params):
         dev = x.device
         x = x.contiguous().float()
         B, cin, H, W = x.shape
@@ -248,6 +251,7 @@ class _UNet(torch.autograd.Function):
             return P[2 * k], P[2 * k + 1]
 
         p_drop = float(drop_p) if training else 0.0
+        sl = float(slope)              # > 0: nn.LeakyReLU(slope) network (icp_weight_policy.py:106)
         ctr = [int(seed) * 64]
 
         def next_seed():
@@ -262,23 +266,23 @@ class _UNet(torch.autograd.Function):
         saved = {}
         # ---- encoder
         w0, b0 = wb(0)
-        a = conv_first(x, w0.float().contiguous(), b0.float().contiguous(), pre)
+        a = conv_first(x, w0.float().contiguous(), b0.float().contiguous(), pre, slope=sl)
         w1, b1 = wb(1)
-        d = conv3x3(a, pk(1), 8, bias=b1, relu=True, drop_p=p_drop, seed=next_seed())
+        d = conv3x3(a, pk(1), 8, bias=b1, relu=True, drop_p=p_drop, seed=next_seed(), slope=sl)
         saved["e0"] = (a, d)
         t = [d]                                   # t[i] = input of encoder block i+1 / skip tensors
         ch = [8, 16, 32, 64, 128, 256]
         for i in range(1, 6):
             wa, ba = wb(2 * i)
             wc, bc = wb(2 * i + 1)
-            a = conv3x3(t[i - 1], pk(2 * i), ch[i], bias=ba, relu=True)
-            if pool_fusable(ch[i], ch[i], B, a.shape[1], a.shape[2]):
+            a = conv3x3(t[i - 1], pk(2 * i), ch[i], bias=ba, relu=True, slope=sl)
+            if sl == 0.0 and pool_fusable(ch[i], ch[i], B, a.shape[1], a.shape[2]):
                 # the second conv writes its 2x2 max-pool as well (no re-read of the full-resolution tensor)
                 pooled = torch.empty(B, a.shape[1] // 2, a.shape[2] // 2, ch[i], dtype=BF16, device=dev)
                 d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed(), pool_out=pooled)
                 t.append(pooled)
             else:
-                d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed())
+                d = conv3x3(a, pk(2 * i + 1), ch[i], bias=bc, relu=True, drop_p=p_drop, seed=next_seed(), slope=sl)
                 t.append(maxpool2(d))
             saved["e%d" % i] = (a, d)
         # ---- decoder
@@ -291,10 +295,10 @@ class _UNet(torch.autograd.Function):
             _, b_a = wb(k0)
             _, b_c = wb(k1)
             u = upsample(cur, skip.shape[1], skip.shape[2])
-            a1 = conv3x3(u, pk(k0), cs, bias=b_a, relu=True)
-            d1 = conv3x3(a1, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed())
-            a2 = conv3x3(skip, pk(k0), cs, bias=b_a, x2=d1, relu=True)
-            d2 = conv3x3(a2, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed())
+            a1 = conv3x3(u, pk(k0), cs, bias=b_a, relu=True, slope=sl)
+            d1 = conv3x3(a1, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed(), slope=sl)
+            a2 = conv3x3(skip, pk(k0), cs, bias=b_a, x2=d1, relu=True, slope=sl)
+            d2 = conv3x3(a2, pk(k1), cs, bias=b_c, relu=True, drop_p=p_drop, seed=next_seed(), slope=sl)
             dsaved.append((u, a1, d1, a2, d2))
             cur = d2
         wf, bf = wb(22)
@@ -312,6 +316,7 @@ class _UNet(torch.autograd.Function):
         # cycle, and the ~4.5 GB of activations hanging off ctx would live until the cyclic GC runs
         ctx.mask = mask.detach()
         ctx.scale = dropout_scale(p_drop)
+        ctx.slope = sl
         ctx.n_params = len(params)
         ctx.norm = bool(norm)
         if ctx.norm:
@@ -332,6 +337,7 @@ class _UNet(torch.autograd.Function):
         x, t, P = ctx.x, ctx.t, ctx.P
         dev = x.device
         s = ctx.scale
+        sl = ctx.slope
         B = x.shape[0]
         gmask = gmask.contiguous().float()
 
@@ -386,9 +392,9 @@ class _UNet(torch.autograd.Function):
             npix = gmask.shape[1] * gmask.shape[2]
             ws = torch.empty(B * 130, dtype=torch.float32, device=dev)
             _lib.check(L.mmk_final_bwd_normalized(_p(d2_4), _p(wf8), _p(ctx.mask), _p(ctx.mask_n), _p(ctx.amax), _p(gmask), B, npix,
-                                                  s, _p(ws[:B * 128]), _p(ws[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _sp(dev)))
+                                                  s, sl, _p(ws[:B * 128]), _p(ws[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _sp(dev)))
         else:
-            _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, _p(gz), _p(g_fw),
+            _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, sl, _p(gz), _p(g_fw),
                                        _p(g_fb), _sp(dev)))
         dbg = DEBUG
         if dbg is not None:
@@ -404,48 +410,48 @@ class _UNet(torch.autograd.Function):
             k0, k1 = 12 + 2 * j, 13 + 2 * j
             # second application
             wgrad(k1, a2, gz)
-            gz_a2 = conv3x3(gz, pkt(k1), cs, relu_src=a2, scale=1.0)
+            gz_a2 = conv3x3(gz, pkt(k1), cs, relu_src=a2, scale=1.0, slope=sl)
             wgrad(k0, skip, gz_a2, x2=d1)
             # skip of dec4 is the post-dropout activation of encoder block 0: apply its factor here
             skip_is_act = (j == 4)
             gsk, gz_d1 = conv3x3(gz_a2, pkt(k0), 2 * cs, split=cs, relu_src=skip if skip_is_act else None,
-                                 scale=s, relu_src2=d1, scale2=s)
+                                 scale=s, relu_src2=d1, scale2=s, slope=sl)
             g_skip[4 - j] = gsk
             # first application
             wgrad(k1, a1, gz_d1)
-            gz_a1 = conv3x3(gz_d1, pkt(k1), cs, relu_src=a1, scale=1.0)
+            gz_a1 = conv3x3(gz_d1, pkt(k1), cs, relu_src=a1, scale=1.0, slope=sl)
             wgrad(k0, u, gz_a1)
-            g_u = conv3x3(gz_a1, pkt(k0), cin_first)
+            g_u = conv3x3(gz_a1, pkt(k0), cin_first, slope=sl)
             if dbg is not None:
                 dbg["gz_a2_%d" % j], dbg["gz_d1_%d" % j], dbg["gz_a1_%d" % j] = gz_a2, gz_d1, gz_a1
                 dbg["g_u_%d" % j], dbg["g_skip_%d" % j] = g_u, gsk.clone()
             if j > 0:
                 prev_d2 = ctx.saved_dec[j - 1][4]
-                gz = upsample_bwd(g_u, prev_d2.shape[1], prev_d2.shape[2], relu_src=prev_d2, scale=s)
+                gz = upsample_bwd(g_u, prev_d2.shape[1], prev_d2.shape[2], relu_src=prev_d2, scale=s, slope=sl)
             else:
                 g_t5 = upsample_bwd(g_u, t[5].shape[1], t[5].shape[2])
         # ---- encoder, i = 5..1
         g_t = g_t5
         for i in range(5, 0, -1):
             a, d = ctx.saved_enc["e%d" % i]
-            gz_d = maxpool2_bwd(d, g_t, s)
+            gz_d = maxpool2_bwd(d, g_t, s, sl)
             if dbg is not None:
                 dbg["g_t_%d" % i], dbg["gz_d_e%d" % i] = g_t.clone(), gz_d
             wgrad(2 * i + 1, a, gz_d)
-            gz_a = conv3x3(gz_d, pkt(2 * i + 1), a.shape[3], relu_src=a, scale=1.0)
+            gz_a = conv3x3(gz_d, pkt(2 * i + 1), a.shape[3], relu_src=a, scale=1.0, slope=sl)
             wgrad(2 * i, t[i - 1], gz_a)
             tgt = g_skip[i - 1]
             cin_i = t[i - 1].shape[3]
             if i == 1:      # t[0] is an activation: factor on the dgrad, then accumulate
-                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True, relu_src=t[0], scale=s)
+                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True, relu_src=t[0], scale=s, slope=sl)
             else:
-                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True)
+                conv3x3(gz_a, pkt(2 * i), cin_i, out=tgt, accumulate=True, slope=sl)
             g_t = tgt
         # ---- encoder block 0
         a0, d0 = ctx.saved_enc["e0"]
         gz_d0 = g_t
         wgrad(1, a0, gz_d0)
-        gz_a0 = conv3x3(gz_d0, pkt(1), 8, relu_src=a0, scale=1.0)
+        gz_a0 = conv3x3(gz_d0, pkt(1), 8, relu_src=a0, scale=1.0, slope=sl)
         g_w0, g_b0 = seg(0).view(8, cin0, 3, 3), seg(1)
         _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), _p(ctx.pre), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0),
                                           _sp(dev)))
@@ -456,11 +462,11 @@ class _UNet(torch.autograd.Function):
             out += [gw, dB[k]]
         out += [g_fw.reshape(1, 8, 1, 1), g_fb]
         out = [g.to(p.dtype) for g, p in zip(out, P)]
-        return (None, None, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None, None) + tuple(out)
 
 
-def unet_mask(module, x, training, seed, norm=False, pre=None):
+def unet_mask(module, x, training, seed, norm=False, pre=None, slope=0.0):
     """sigmoid mask (B,H,W) fp32 of the module's network on fp32 NCHW input x; ``norm``: divided by its
     per-image maximum (the policy's ``norm_weights``), inside the same autograd node; ``pre`` (C,2): the
     input is (x - pre[c,0]) * pre[c,1], applied by the first layer while it loads x."""
-    return _UNet.apply(x, pre, float(module.dropout), int(seed), bool(training), bool(norm), *param_list(module))
+    return _UNet.apply(x, pre, float(module.dropout), int(seed), bool(training), bool(norm), float(slope), *param_list(module))

@@ -31,6 +31,9 @@ def lib():
         _lib.mmk_oracle_transform.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, f32p]
         _lib.mmk_oracle_transform.restype = None
+        f64p = ctypes.POINTER(ctypes.c_double)
+        _lib.mmk_oracle_blend4_f64.argtypes = [f64p] * 8 + [ctypes.c_long, f64p]
+        _lib.mmk_oracle_blend4_f64.restype = None
     return _lib
 
 
@@ -61,4 +64,13 @@ def transform(src, T, d):
     B, N, _ = src.shape
     out = np.empty((B, N, d), dtype=np.float32)
     lib().mmk_oracle_transform(sp, Tp, B, N, d, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def blend4_f64(taps, weights):
+    """fma(t3, w3, fma(t2, w2, fma(t1, w1, t0 * w0))) element-wise in fp64 (see nn_search.c)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in list(taps) + list(weights)]
+    out = np.empty_like(arrs[0])
+    ptrs = [a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for a in arrs]
+    lib().mmk_oracle_blend4_f64(*ptrs, out.size, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return out

@@ -82,3 +82,18 @@ void mmk_oracle_transform(const float *src, const float *T, int B, int N, int d,
         }
     }
 }
+
+/*
+ * Four-tap blend of F.grid_sample(bilinear) in fp64 as PyTorch's CPU kernel evaluates it
+ * (ATen/native/cpu/GridSamplerKernel.cpp, compiled with FMA contraction): the chain
+ *   fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw)))
+ * — found by comparing candidate orders with the reference's radar_cartesian_to_polar
+ * (mm_masking/radar_utils.py:338-372) on random input: only this one is bit-identical.
+ */
+void mmk_oracle_blend4_f64(const double *t0, const double *t1, const double *t2, const double *t3,
+                           const double *w0, const double *w1, const double *w2, const double *w3,
+                           long n, double *out)
+{
+    for (long i = 0; i < n; ++i)
+        out[i] = fma(t3[i], w3[i], fma(t2[i], w2[i], fma(t1[i], w1[i], t0[i] * w0[i])));
+}
