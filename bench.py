@@ -65,10 +65,12 @@ def nn_algorithmic_bytes(B):
     return B * (4 * DIM * N_PAD + 4 * DIM * M_PAD + 8 * N_PAD)
 
 
-def cpu_baseline(params_like, sample_pairs=4, timed_steps=3):
+def cpu_baseline(params_like, sample_pairs=16, timed_steps=3, steps_8_threads=2):
     """The cpu_baseline leg — the only part of bench.py that touches oracle/: the oracle's
-    PyTorch-CPU port of the same train step (oracle/train_ref.py) timed on a bounded sample
-    (`sample_pairs` pairs per step, 1 warm-up + `timed_steps` steps)."""
+    PyTorch-CPU port of the same train step (oracle/train_ref.py) timed on a bounded sample:
+    `sample_pairs` pairs per step (16 = the reference's train batch, train_icp_weights.py:374),
+    1 warm-up + `timed_steps` steps on every usable core, then `steps_8_threads` steps on 8 threads (the
+    reference's OMP_NUM_THREADS=8, scripts/setup_container.sh:25)."""
     from mm_masking_amd import synthetic
     from oracle import radar_ref, train_ref
     torch.set_num_threads(usable_cores())
@@ -92,11 +94,30 @@ def cpu_baseline(params_like, sample_pairs=4, timed_steps=3):
         step.step(batch)
         progress("cpu_baseline: timed step %d/%d done, %.1f s" % (i + 1, timed_steps, time.time() - t0))
     dt = time.time() - t0
-    return {"value": sample_pairs * timed_steps / dt, "unit": "pairs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d timed steps of B=%d after 1 warm-up (fp32 U-Net + 10-iter pt2pl Huber ICP fwd+bwd + Adam; "
-                      "CFAR/polar->Cartesian outside the step as in the reference's cached Dataset), %.1f s"
-                      % (timed_steps, sample_pairs, dt)}
+    res = {"value": sample_pairs * timed_steps / dt, "unit": "pairs/s", "cores": torch.get_num_threads(),
+           "kind": "port",
+           "sample": "%d timed steps of B=%d after 1 warm-up (fp32 U-Net + 10-iter pt2pl Huber ICP fwd+bwd + Adam; "
+                     "CFAR/polar->Cartesian outside the step as in the reference's cached Dataset), %.1f s"
+                     % (timed_steps, sample_pairs, dt)}
+    if steps_8_threads > 0 and torch.get_num_threads() != 8:
+        n_all = torch.get_num_threads()
+        torch.set_num_threads(8)
+        os.environ["OMP_NUM_THREADS"] = "8"           # the C restatement of the NN search reads it per parallel region
+        try:
+            import ctypes as _ct
+            _ct.CDLL("libgomp.so.1").omp_set_num_threads(8)
+        except OSError:
+            pass
+        t0 = time.time()
+        for i in range(steps_8_threads):
+            step.step(batch)
+            progress("cpu_baseline: 8-thread step %d/%d done, %.1f s" % (i + 1, steps_8_threads, time.time() - t0))
+        dt8 = time.time() - t0
+        res["value_8_threads"] = sample_pairs * steps_8_threads / dt8
+        res["sample_8_threads"] = "%d timed steps of B=%d on 8 threads (the reference's OMP_NUM_THREADS), %.1f s" % (
+            steps_8_threads, sample_pairs, dt8)
+        torch.set_num_threads(n_all)
+    return res
 
 
 def conv_stack_rate(model, raw, params, device, reps=3):
@@ -125,6 +146,40 @@ def conv_stack_rate(model, raw, params, device, reps=3):
             "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
             "flop": "3 x %.2f GFLOP/sample (fwd + data grad + weight grad), B=%d" % (gf, B),
             "note": "layers with <= 16 channels at 640x640 are HBM-bound (arithmetic intensity ~70 FLOP/B)"}
+
+
+def grid_engine_block(model, one_step, first, B, L, steps=5):
+    """Side measurement (never `value`): the same step with the exact uniform-grid NN engine (identical
+    correspondences), its launches timed with the same HIP-event hook."""
+    from mm_masking_amd import _lib
+    from mm_masking_amd.dICP.ICP import _IcpFunction
+    engines = (model.ICP_alg.nn_search, model.ICP_alg_inference.nn_search)
+    model.ICP_alg.nn_search = model.ICP_alg_inference.nn_search = "grid"
+    try:
+        for i in range(2):
+            one_step(first + i)
+        torch.cuda.synchronize()
+        cap = steps * ICP_ITERS + 8
+        _lib.check(L.mmk_nn_profile_begin(cap))
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(first + 2 + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms = (ctypes.c_float * cap)()
+        n_rec = ctypes.c_int32(0)
+        _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
+        g_ms = np.array(ms[:min(n_rec.value, cap)], dtype=np.float64)
+        act = float(_IcpFunction.last_active[:ICP_ITERS].float().sum(dim=1).mean().item())
+        avg_s = float(g_ms.mean()) * 1e-3
+        alg = nn_algorithmic_bytes(1) * act
+        return {"bound": "hbm", "kernel": "grid_nn_kernel<2>", "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "launches_timed": int(len(g_ms)), "active_pairs_per_launch": act, "algorithmic_bytes_per_launch": alg,
+                "ms_per_step": dt / steps * 1e3, "pairs_per_s": B * steps / dt,
+                "note": "same algorithmic bytes as the brute-force launch (the engine reads a binned copy of the target)"}
+    finally:
+        model.ICP_alg.nn_search, model.ICP_alg_inference.nn_search = engines
 
 
 def pose_parity(model, params, device, pairs=2):
@@ -170,6 +225,7 @@ def main():
                          "SURVEY 8f.3): a side measurement, not the headline configuration")
     ap.add_argument("--settle", type=int, default=40, help="untimed settling steps before the warm-up (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid", action="store_true", help="skip the side measurement of the exact grid NN engine")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
@@ -295,12 +351,20 @@ def main():
     result = None
     if rank == 0:
         nn_avg_s = float(nn_ms.mean()) * 1e-3 if len(nn_ms) else float("nan")
-        alg_bytes = nn_algorithmic_bytes(B)
+        # frozen pairs (||delta|| < tolerance) skip the NN kernel: price a launch by the pairs that ran
+        active_pairs = float(B)
+        from mm_masking_amd.dICP.ICP import _IcpFunction
+        if _IcpFunction.last_active is not None:
+            act = _IcpFunction.last_active[:ICP_ITERS].float().sum(dim=1)       # (K,): active pairs per launch, last step
+            active_pairs = float(act.mean().item())
+        alg_bytes = nn_algorithmic_bytes(1) * active_pairs
         achieved = alg_bytes / nn_avg_s / 1e9
-        evals = B * N_PAD * M_PAD                  # distance evaluations per launch
+        evals = active_pairs * N_PAD * M_PAD       # distance evaluations per launch
+        # HBM bytes per launch from the PMC counters: measured in a separate rocprofv3 --pmc pass of this same
+        # command (scripts/prof_nn.py -> profiles/r02_nn_traffic.json, committed); null when that file is absent
         traffic = None
-        tr_file = os.path.join(ROOT, "profiles", "nn_traffic.json")
-        if os.path.exists(tr_file):
+        tr_file = os.path.join(ROOT, "profiles", "r02_nn_traffic.json")
+        if os.path.exists(tr_file) and model.ICP_alg.nn_search == "brute":
             traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
         result = {
             "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,
@@ -321,6 +385,7 @@ def main():
                          "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else "nn_search_kernel<2,16,2>",
                          "nn_engine": model.ICP_alg.nn_search, "launches_timed": int(len(nn_ms)),
                          "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                         "active_pairs_per_launch": active_pairs,
                          "note": "north_star names the HBM roofline; brute force does %.3g distance evaluations per "
                                  "launch over those bytes (~2.2 kFLOP/B), so the binding roofline is fp32 VALU" % evals,
                          "valu": {"pair_evals_per_s": evals / nn_avg_s,
@@ -330,6 +395,8 @@ def main():
         }
         if world == 1:
             result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)
+            if model.ICP_alg.nn_search == "brute" and not args.no_grid:
+                result["roofline_grid"] = grid_engine_block(model, one_step, args.warmup + args.steps, B, L)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(params)
             if not args.no_parity:

@@ -268,9 +268,11 @@ int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int
  * pre (may be NULL): 2 floats per input channel (offset, reciprocal scale); the kernels then read
  * (x - offset) * rscale — the policy's per-channel min-max normalisation
  * (icp_weight_policy.py:151-155) applied while loading.  mmk_channel_minmax fills pre with
- * (min, 1 / (max - min)) over (B,H,W) per channel; part: C*2048 floats of workspace. */
+ * (min, 1 / (max - min)) over (B,H,W) per channel; part: C*2048 floats of workspace; minmax (optional):
+ * the raw (min, max) pairs, what a data-parallel job reduces over its ranks to keep the normalisation
+ * batch-global (mm_masking_amd/icp_weight_policy.py: params["global_minmax"]). */
 int mmk_channel_minmax(const float *x /*B,C,hw*/, int32_t B, int32_t C, int64_t hw, float *part,
-                       float *pre /*C*2*/, void *stream);
+                       float *pre /*C*2*/, float *minmax /*C*2 or NULL*/, void *stream);
 int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre,
                    int32_t B, int32_t H, int32_t Wd, float leaky_slope, void *y, void *stream);
 int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B,

@@ -99,7 +99,7 @@ def _declare(lib):
         "mmk_conv3x3_wgrad_slices": (i32, [i32, i32, i32, i32, i32, i32]),
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
         "mmk_conv3x3_pool_fusable": (ctypes.c_int32, [i32, i32, i32, i32, i32]),
-        "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp]),
+        "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
@@ -156,6 +156,15 @@ def check(rc):
 
 
 def stream_ptr(device=None):
+    """The current PyTorch HIP stream of ``device`` as a void*.  The C entry points launch on the calling
+    thread's *current* HIP device (include/mmk.h), so a tensor that lives on another device than the
+    current one would meet a foreign stream handle: refuse that instead of faulting."""
+    if device is not None:
+        idx = device.index if isinstance(device, torch.device) else int(device)
+        if idx is not None and idx != torch.cuda.current_device():
+            raise MmkError("tensors live on cuda:%d but the current HIP device is cuda:%d: call torch.cuda.set_device() "
+                           "(one process per GPU) or wrap the call in `with torch.cuda.device(...)`"
+                           % (idx, torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

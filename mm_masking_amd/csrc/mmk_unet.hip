@@ -2552,7 +2552,8 @@ __global__ __launch_bounds__(256) void channel_minmax_partial_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(256) void channel_minmax_final_kernel(const float *__restrict__ part, int C, float *__restrict__ pre)
+__global__ __launch_bounds__(256) void channel_minmax_final_kernel(const float *__restrict__ part, int C, float *__restrict__ pre,
+                                                                   float *__restrict__ minmax)
 {
     __shared__ float shn[4], shx[4];
     const int c = blockIdx.x;
@@ -2576,6 +2577,10 @@ __global__ __launch_bounds__(256) void channel_minmax_final_kernel(const float *
         mx = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
         pre[2 * c] = mn;
         pre[2 * c + 1] = 1.0f / (mx - mn);
+        if (minmax) {
+            minmax[2 * c] = mn;
+            minmax[2 * c + 1] = mx;
+        }
     }
 }
 
@@ -2731,13 +2736,14 @@ extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t
 
 static unsigned nblk(size_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
-extern "C" int mmk_channel_minmax(const float *x, int32_t B, int32_t C, int64_t hw, float *part, float *pre, void *stream)
+extern "C" int mmk_channel_minmax(const float *x, int32_t B, int32_t C, int64_t hw, float *part, float *pre, float *minmax,
+                                  void *stream)
 {
     MMK_REQUIRE(x && part && pre && B >= 1 && C >= 1 && C <= 65535 && hw >= 1, "mmk_channel_minmax: bad argument");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_minmax_partial_kernel, dim3(MM_BLOCKS, C), dim3(256), 0, st, x, B, C, (size_t)hw, part);
     MMK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(channel_minmax_final_kernel, dim3(C), dim3(256), 0, st, part, C, pre);
+    hipLaunchKernelGGL(channel_minmax_final_kernel, dim3(C), dim3(256), 0, st, part, C, pre, minmax);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

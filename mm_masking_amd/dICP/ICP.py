@@ -32,10 +32,13 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    buf = _ws_cache.get(device.index)
+    """Scratch of the ICP kernels, one buffer per (device, stream): calls enqueued on different streams
+    (e.g. micro-batches overlapped on side streams) must not share scratch."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[device.index] = buf
+        _ws_cache[key] = buf
     return buf
 
 
@@ -68,10 +71,12 @@ def _forward(p, src, tgt, weight, T_init):
 class _IcpFunction(torch.autograd.Function):
     """Autograd hook: forward = K unrolled iterations in HIP, backward = the
     hand-derived reverse sweep (no autograd graph through the iterations)."""
+    last_active = None
 
     @staticmethod
     def forward(ctx, weight, T_init, src, tgt, p):
         T_out, st, _ = _forward(p, src, tgt, weight, T_init)
+        _IcpFunction.last_active = st["active"]      # (K+1,B): pairs still iterating (measurement: bench.py)
         ctx.p = p
         ctx.save_for_backward(weight, src, tgt, st["idx"], st["T"], st["delta"], st["A"], st["active"])
         return T_out

@@ -84,6 +84,9 @@ class LearnICPWeightPolicy(nn.Module):
         self.unet_backend = params.get("unet_backend", "hip")
         if self.unet_backend not in ("hip", "torch"):
             raise ValueError("unet_backend must be 'hip' or 'torch' (got %r)" % (self.unet_backend,))
+        # data-parallel jobs: reduce the min-max normalisation's extrema over the ranks, so that it stays
+        # global over the whole batch as in the single-process reference (icp_weight_policy.py:151-155)
+        self.global_minmax = bool(params.get("global_minmax", False))
         self._step = 0
 
         self.mean_num_pts = 0.0
@@ -195,7 +198,7 @@ class LearnICPWeightPolicy(nn.Module):
                     # min-max normalisation folded into the first layer's loads: one min/max pass, no
                     # normalised copy of the image
                     net_in = raw_in.contiguous().float()
-                    pre = unet_hip.channel_minmax(net_in)
+                    pre = unet_hip.channel_minmax(net_in, global_reduce=self.global_minmax)
                 else:
                     net_in, pre = self._normalize_channels(raw_in), None
                 # (the amax normalisation below rides inside the same autograd node)

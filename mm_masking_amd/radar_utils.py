@@ -40,7 +40,7 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (device.index, "radar")
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "radar")
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

@@ -175,13 +175,23 @@ def conv_first(x, w, b, pre=None, slope=0.0):
     return y
 
 
-def channel_minmax(x):
+def channel_minmax(x, process_group=None, global_reduce=False):
     """(min, 1 / (max - min)) per channel of fp32 (B,C,H,W) over (B,H,W) -> (C,2) fp32: the offset and
-    reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155)."""
+    reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155).
+    ``global_reduce``: in a data-parallel job the minimum / maximum are reduced over the ranks (one MAX
+    all-reduce of 2C floats), so that the normalisation stays global over the whole batch as in the
+    single-process reference."""
     B, C, H, W = x.shape
     part = torch.empty(C * 2048, dtype=torch.float32, device=x.device)
     pre = torch.empty(C, 2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mmk_channel_minmax(_p(x), B, C, H * W, _p(part), _p(pre), _sp(x.device)))
+    import torch.distributed as dist
+    reduce = global_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+    mm = torch.empty(C, 2, dtype=torch.float32, device=x.device) if reduce else None
+    _lib.check(_lib.lib().mmk_channel_minmax(_p(x), B, C, H * W, _p(part), _p(pre), _p(mm), _sp(x.device)))
+    if reduce:
+        t = torch.stack((-mm[:, 0], mm[:, 1]), dim=1)            # max(-min) = -min over the ranks
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=process_group)
+        pre = torch.stack((-t[:, 0], 1.0 / (t[:, 1] + t[:, 0])), dim=1).contiguous()
     return pre
 
 

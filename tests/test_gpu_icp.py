@@ -300,3 +300,66 @@ def test_config5_50k_fp32_gate():
     assert np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max() <= 1e-4
     # and the ICP actually localises: back to identity within a few cm
     assert np.abs(Tg[:, :2, 3]).max() < 0.1 and np.abs(Tg[:, 1, 0]).max() < 5e-3
+
+
+# ----------------------------------------------------------------------------- known answers built outside our code
+import dicp_kat as kat  # noqa: E402
+
+
+def _run_hip(icp_type, src, tgt, T0, dim, K, loss=None, trim=50.0, weight=None, tol=1e-12):
+    icp = ICP(icp_type, differentiable=False, max_iterations=K, tolerance=tol)
+    icp.check_every = 0 if K < 8 else icp.check_every
+    lf = None if loss is None else {"name": loss, "metric": 1.0}
+    w = None if weight is None else torch.from_numpy(np.asarray(weight, np.float32))[None].to(DEV)
+    T = icp.icp(torch.from_numpy(src)[None].to(DEV), torch.from_numpy(tgt)[None].to(DEV),
+                T_init=torch.from_numpy(np.asarray(T0, np.float32))[None].to(DEV), weight=w, trim_dist=trim, loss_fn=lf, dim=dim)["T"]
+    return T[0].cpu().numpy(), icp.last_state
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("icp_type", ["pt2pt", "pt2pl"])
+def test_kat_noise_free_copy_recovers_transform(icp_type, dim):
+    """Noise-free copy clouds (tests/dicp_kat.py), offset inside the reference's perturbation envelope: the HIP ICP
+    recovers the transform to north_star's gate 1e-3 m / 1e-4 rad (in fact to fp32 rounding of the clouds)."""
+    src, tgt, T_true = kat.jittered_grid_pair(dim, seed=3 + dim)
+    T, _ = _run_hip(icp_type, src, tgt, np.eye(4), dim, K=30)
+    dt, da = kat.pose_errors(T, T_true, dim)
+    assert dt <= 1e-3 and da <= 1e-4, (dt, da)
+    assert dt <= 2e-5 and da <= 2e-6, (dt, da)
+
+
+@pytest.mark.parametrize("icp_type,dim,loss", [("pt2pt", 2, None), ("pt2pl", 2, "huber"), ("pt2pt", 3, "cauchy"), ("pt2pl", 3, None),
+                                               ("pt2pl", 2, "cauchy"), ("pt2pt", 2, "huber")])
+def test_kat_one_gauss_newton_step_from_definitions(icp_type, dim, loss):
+    """One HIP iteration against a step computed from the definitions alone (finite-difference Jacobian of
+    scipy's matrix exponential, exhaustive argmin, numpy solve)."""
+    src, tgt, _ = kat.jittered_grid_pair(dim, seed=11)
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.2, 1.0, len(src)).astype(np.float32)
+    T0 = kat.exp_se3([0.3, -0.2, 0.1 if dim == 3 else 0, 0.01 if dim == 3 else 0, 0, 0.03]).astype(np.float32)
+    T1, delta, idx = kat.gauss_newton_step(src, tgt, T0, w, icp_type, dim, loss=loss, k=1.0, trim=5.0)
+    T, st = _run_hip(icp_type, src, tgt, T0, dim, K=1, loss=loss, trim=5.0, weight=w)
+    assert np.array_equal(st["idx"][0, 0].cpu().numpy(), idx)
+    got = st["delta"][0, 0].cpu().numpy()[:len(delta)]
+    np.testing.assert_allclose(got, delta, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(T, T1, atol=3e-6)
+
+
+@pytest.mark.parametrize("r2,loss", [(1.0 - 1e-3, "huber"), (1.0, "huber"), (1.0 + 1e-3, "huber"), (3.0, "huber"),
+                                     (0.7, "cauchy"), (2.0, None)])
+def test_kat_huber_kink_closed_form(r2, loss):
+    src, tgt, (n1, n2, r1) = kat.two_group_lines(r2)
+    _, st = _run_hip("pt2pl", src, tgt, np.eye(4), 2, K=1, loss=loss, trim=5.0)
+    d = st["delta"][0, 0].cpu().numpy()
+    want = kat.two_group_delta_y(r2, n1, n2, r1, loss, 1.0, 5.0)
+    assert abs(d[1] - want) <= 2e-7 * max(1.0, abs(want)) and abs(d[0]) < 1e-9 and abs(d[2]) < 1e-9
+
+
+@pytest.mark.parametrize("r2,kept", [(5.0 - 1e-3, True), (5.0, False), (5.0 + 1e-3, False)])
+def test_kat_trim_boundary_closed_form(r2, kept):
+    src, tgt, (n1, n2, r1) = kat.two_group_lines(r2)
+    _, st = _run_hip("pt2pl", src, tgt, np.eye(4), 2, K=1, loss=None, trim=5.0)
+    d = st["delta"][0, 0].cpu().numpy()
+    want = kat.two_group_delta_y(r2, n1, n2, r1, None, 1.0, 5.0)
+    assert abs(d[1] - want) <= 2e-7 * max(1.0, abs(want))
+    assert (abs(want - r1) < 1e-7) == (not kept)

@@ -10,7 +10,6 @@ import torch
 from mm_masking_amd import synthetic
 from mm_masking_amd import train_icp_weights as trn
 from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
-from oracle import train_ref, unet_ref
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -23,15 +22,52 @@ def _params(**over):
     return p
 
 
+def _grad_vectors(g, tag, names):
+    """Per-tensor gradient heads / norms of unet_grads.npz (tests/golden/make_golden_r2.py)."""
+    heads, off = {}, 0
+    for k, n in zip(names, g["head_len_" + tag]):
+        heads[k] = g["head_" + tag][off:off + n]
+        off += n
+    return heads, dict(zip(names, g["norm_" + tag])), dict(zip(names, g["numel_" + tag]))
+
+
+def _check_grads_against_golden(model, g, tag, names, cos_min, rel_max):
+    """HIP (bf16 storage) parameter gradients against the reference module's fp32 gradient vectors:
+    direction per tensor (cosine of the stored head; whole tensor when it has <= 4096 elements), norm per
+    tensor, and the global relative L2 error over the stored elements."""
+    heads, norms, numel = _grad_vectors(g, tag, names)
+    gp = dict(model.named_parameters())
+    num = den = 0.0
+    worst = (1.0, None)
+    for k in names:
+        got = gp[k].grad.detach().float().reshape(-1).cpu().numpy()
+        want = heads[k]
+        h = got[:len(want)]
+        num += float(((h - want) ** 2).sum())
+        den += float((want ** 2).sum())
+        c = float((h * want).sum() / (np.linalg.norm(h) * np.linalg.norm(want) + 1e-30))
+        if c < worst[0]:
+            worst = (c, k)
+        assert abs(np.linalg.norm(got) / norms[k] - 1.0) < 3 * rel_max, (k, np.linalg.norm(got), norms[k])
+    rel = (num / den) ** 0.5
+    assert worst[0] > cos_min, worst
+    assert rel < rel_max, rel
+    return rel, worst
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_unet_golden_fp32(golden_dir, tag):
+def test_unet_hip_backend_golden(golden_dir, tag):
+    """The hand-written bf16 U-Net (the only backend on a HIP device) against the reference module's golden
+    mask and per-tensor gradient vectors: a = default network, b = 3 input channels (fft | cfar | range),
+    LeakyReLU(0.1), log transform + standardisation (icp_weight_policy.py:104-125,136-159)."""
     g = np.load(os.path.join(golden_dir, "unet.npz"), allow_pickle=False)
-    over = {"amp_dtype": torch.float32, "unet_backend": "torch"}
+    gv = np.load(os.path.join(golden_dir, "unet_grads.npz"), allow_pickle=False)
+    over = {}
     if tag == "b":
-        over.update({"cfar_input": True, "range_input": True, "leaky": True, "normalize": ["standardize"],
-                     "log_transform": True})
+        over = {"cfar_input": True, "range_input": True, "leaky": True, "normalize": ["standardize"], "log_transform": True}
     torch.manual_seed(1234)
     model = LearnICPWeightPolicy(_params(**over)).to(DEV)
+    assert model.unet_backend == "hip"
     model.train()
     names = [str(n) for n in g["names_" + tag]]
     sd = model.state_dict()
@@ -42,43 +78,52 @@ def test_unet_golden_fp32(golden_dir, tag):
         model.range_mask = torch.from_numpy(g["range_b"]).to(DEV)
     scan = {"fft_data": torch.from_numpy(g["x_" + tag]), "fft_cfar": torch.from_numpy(g["cfar_" + tag]),
             "raw_pc": torch.zeros(2, 4, 3)}
-    m = model(scan, {"pc": torch.zeros(2, 4, 6)}, torch.eye(4).repeat(2, 1, 1), mask_only=True)
-    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_" + tag], atol=5e-5)
+    from mm_masking_amd import unet_hip
+    unet_hip.DEBUG = {}
+    try:
+        m = model(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+        assert "fwd" in unet_hip.DEBUG                                 # the hand-written path ran
+    finally:
+        unet_hip.DEBUG = None
+    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_" + tag], atol=2e-3 if tag == "a" else 4e-3)
     (m * torch.from_numpy(g["gsel_" + tag]).to(DEV)).sum().backward()
     grads = dict(model.named_parameters())
     ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
-    # MIOpen picks other fp32 conv algorithms (e.g. Winograd) than the CPU reference
-    np.testing.assert_allclose(ga, g["gabs_" + tag], rtol=2e-2, atol=1e-4)
+    assert np.all(np.isfinite(ga))
+    # bf16 storage of 33 layers of activations and gradient tensors at random init (small, noisy gradients):
+    # direction and size per tensor, global relative error (measured values in DESIGN.md)
+    _check_grads_against_golden(model, gv, tag, names, cos_min=0.90, rel_max=0.15)
 
 
-def test_unet_hip_backend_golden(golden_dir):
-    """The hand-written bf16 U-Net (default backend) against the reference module's golden mask."""
-    g = np.load(os.path.join(golden_dir, "unet.npz"), allow_pickle=False)
+def test_unet_hip_golden_640(golden_dir):
+    """640 x 640 (the network's real input size), one image: mask against the reference module's
+    (sub-sampled every 5th pixel + sum), every parameter-gradient vector, and the full gradients of
+    encoder.0.0 and final_layer.0 (tests/golden/make_golden_r2.py)."""
+    gv = np.load(os.path.join(golden_dir, "unet_grads.npz"), allow_pickle=False)
+    H = 640
+    xin = np.random.default_rng(199).uniform(0.0, 1, size=(1, H, H)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:H]
+    for cx, cy, s in np.random.default_rng(198).uniform(40, 600, size=(30, 3)):
+        xin[0] += 2.0 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * (2 + s / 100.0) ** 2)).astype(np.float32)
+    xin = (xin / xin.max()).astype(np.float32)
+    assert abs(xin.astype(np.float64).sum() - float(gv["x_c_sum"])) < 1e-6 * float(gv["x_c_sum"])
     torch.manual_seed(1234)
     model = LearnICPWeightPolicy(_params()).to(DEV)
-    assert model.unet_backend == "hip"
     model.train()
-    scan = {"fft_data": torch.from_numpy(g["x_a"]), "fft_cfar": torch.from_numpy(g["cfar_a"]), "raw_pc": torch.zeros(2, 4, 3)}
-    m = model(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
-    np.testing.assert_allclose(m.detach().cpu().numpy(), g["mask_a"], atol=2e-3)
-    (m * torch.from_numpy(g["gsel_a"]).to(DEV)).sum().backward()
-    names = [str(n) for n in g["names_a"]]
-    grads = dict(model.named_parameters())
-    ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
-    assert np.all(np.isfinite(ga)) and np.abs(ga / g["gabs_a"] - 1).max() < 0.6     # bf16 storage: see test_gpu_unet_kernels
-
-
-def test_unet_bf16_close_to_fp32():
-    torch.manual_seed(7)
-    m32 = LearnICPWeightPolicy(_params(amp_dtype=torch.float32, unet_backend="torch")).to(DEV)
-    m16 = LearnICPWeightPolicy(_params(unet_backend="torch")).to(DEV)
-    m16.load_state_dict(m32.state_dict())
-    x = torch.rand(2, 128, 128)
-    scan = {"fft_data": x, "fft_cfar": x, "raw_pc": torch.zeros(2, 4, 3)}
-    a = m32(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
-    b = m16(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
-    assert a.dtype == b.dtype == torch.float32
-    assert (a - b).abs().max().item() < 0.03          # bf16 conv stack, 33 layers deep
+    scan = {"fft_data": torch.from_numpy(xin), "fft_cfar": torch.zeros(1, H, H), "raw_pc": torch.zeros(1, 4, 3)}
+    m = model(scan, {"pc": torch.zeros(1, 4, 6)}, None, mask_only=True)
+    mc = m.detach().cpu().numpy()
+    np.testing.assert_allclose(mc[:, ::5, ::5], gv["mask_c_sub"], atol=3e-3)
+    assert abs(mc.astype(np.float64).sum() / float(gv["mask_c_sum"]) - 1.0) < 1e-3
+    gsel = torch.from_numpy(np.random.default_rng(197).normal(size=(1, H, H)).astype(np.float32)).to(DEV)
+    (m * gsel).sum().backward()
+    names = [str(n) for n in gv["names_c"]]
+    _check_grads_against_golden(model, gv, "c", names, cos_min=0.90, rel_max=0.15)
+    gp = dict(model.named_parameters())
+    for key, name in (("g_enc00_w_c", "encoder.0.0.weight"), ("g_enc00_b_c", "encoder.0.0.bias"),
+                      ("g_final_w_c", "final_layer.0.weight"), ("g_final_b_c", "final_layer.0.bias")):
+        got, want = gp[name].grad.cpu().numpy(), gv[key]
+        assert np.linalg.norm(got - want) <= 0.10 * np.linalg.norm(want) + 1e-12, (name, got, want)
 
 
 def _small_batch(B=2, max_pts=2048, m_valid=3000):
@@ -119,36 +164,19 @@ def test_forward_signature_and_modes():
 
 
 def test_train_step_matches_cpu_port():
-    """One full step (fp32 convs, no dropout) against the oracle's CPU port:
-    same loss, same mask, same pose, parameter gradients close."""
+    """One full step on the product's default path (hand-written bf16 U-Net, no dropout) against the
+    oracle's fp32 CPU port, small size (the BASELINE-size versions are in test_gpu_step_parity.py):
+    mask within bf16 tolerance, and -- with the HIP mask fed to the oracle's downstream -- the same
+    correspondences, pose, loss and mask gradient; parameter gradients within the bf16 budget."""
+    import step_parity
     raw, params, batch = _small_batch(B=2, max_pts=2048)
-    params = dict(params, amp_dtype=torch.float32, unet_backend="torch")
-    torch.manual_seed(1234)
-    model = LearnICPWeightPolicy(params).to(DEV)
-    model.train()
-    opt = trn.make_optimizer(model, params)
-    lw = trn.loss_weights_from(params)
-    opt.zero_grad()
-    T, mask, nn0 = model(batch["loc_data"], batch["map_data"], raw["T_init"])
-    loss, comp = trn.eval_training_loss(T, mask, nn0, raw["T_gt"], batch["loc_data"], batch["map_data"], model,
-                                        loss_weights=lw)
-    loss.backward()
-
-    ref = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn={"name": "huber", "metric": 1.0}, max_iter=5, dim=2,
-                                 dropout=0.0, seed=1234)
-    cb = {"fft_data": batch["loc_data"]["fft_data"].cpu(), "raw_pc": batch["loc_data"]["raw_pc"].cpu(),
-          "filtered_pc": batch["loc_data"]["filtered_pc"].cpu(), "map_pc": raw["map_pc"].cpu(),
-          "T_init": raw["T_init"].cpu(), "T_gt": raw["T_gt"].cpu()}
-    Tr, maskr, wr = ref.forward(cb, training=True)
-    lossr, _ = train_ref.eval_training_loss(Tr, maskr, None, cb["T_gt"], cb["fft_data"], None, cb["map_pc"], None, lw)
-    lossr.backward()
-    np.testing.assert_allclose(mask.detach().cpu().numpy(), maskr.detach().numpy(), atol=2e-4)
-    np.testing.assert_allclose(T.detach().cpu().numpy(), Tr.detach().numpy(), atol=2e-3)
-    assert abs(loss.item() - lossr.item()) < 2e-3 * max(1.0, abs(lossr.item()))
-    gp = dict(model.named_parameters())
-    num = sum(((gp[k].grad.cpu() - ref.sd[k].grad) ** 2).sum().item() for k in ref.sd)
-    den = sum((ref.sd[k].grad ** 2).sum().item() for k in ref.sd)
-    assert num <= (0.05 ** 2) * den, (num, den)
+    res = step_parity.run(raw, params, batch, max_iter=5, seed=1234)
+    assert res["mask_max_abs"] < 3e-3, res
+    assert res["idx_mismatches"] == 0, res
+    assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
+    assert res["loss_rel_err"] < 1e-4, res
+    assert res["mask_grad_rel"] <= 2e-3, res
+    assert res["param_grad_rel"] < 0.15 and res["param_grad_cos_min"] > 0.85, res
 
 
 def test_training_reduces_loss_bf16():

@@ -1,0 +1,57 @@
+"""Whole-step parity at BASELINE.json's workload sizes on the product's default backend:
+configs[1] (B=16, 400x3360 polar -> Cartesian -> U-Net fwd + 10-iteration pt2pl Huber dICP fwd, no backward)
+and configs[2] (B=32, N=5120, M=20480, full step fwd + bwd).  The body is tests/step_parity.py."""
+import json
+import os
+
+import pytest
+import torch
+
+from mm_masking_amd import synthetic
+from mm_masking_amd import train_icp_weights as trn
+
+import step_parity
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+N_PAD, M_VALID, M_PAD = 5120, 20000, 20480
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _batch(B, first):
+    params = trn.default_params(DEV)
+    params.update({"dropout": 0.0})
+    raw = synthetic.make_batch(list(range(first, first + B)), device=DEV, m_valid=M_VALID, m_pad=M_PAD)
+    return raw, params, trn.prepare_batch(raw, params, max_loc_pts=N_PAD)
+
+
+def _record(name, res):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "step_parity_%s.json" % name), "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_config1_b16_forward_parity():
+    raw, params, batch = _batch(16, 2000)
+    assert batch["loc_data"]["fft_data"].shape == (16, 640, 640) and raw["fft_polar"].shape == (16, 400, 3360)
+    res = step_parity.run(raw, params, batch, max_iter=10, backward=False)
+    _record("config1", res)
+    assert res["mask_max_abs"] < 4e-3, res                       # bf16 network vs the fp32 oracle
+    assert res["idx_mismatches"] == 0, res                       # HIP mask fed downstream: indices bit-exact
+    assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
+
+
+def test_config2_b32_full_step_parity():
+    raw, params, batch = _batch(32, 3000)
+    res = step_parity.run(raw, params, batch, max_iter=10, backward=True)
+    _record("config2", res)
+    assert res["mask_max_abs"] < 4e-3, res
+    assert res["idx_mismatches"] == 0 and res["icp_iters"] == 10, res
+    assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
+    assert res["loss_rel_err"] < 1e-4, res
+    assert res["mask_grad_rel"] <= 2e-3, res
+    # parameter gradients, bf16 storage vs fp32 (stated budget)
+    assert res["param_grad_rel"] < 0.15 and res["param_grad_cos_min"] > 0.85, res

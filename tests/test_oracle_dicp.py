@@ -121,3 +121,72 @@ def test_oracle_gradient_finite_difference():
         wm = w.detach().clone(); wm[0, i] -= eps
         fd = (f(wp) - f(wm)).item() / (2 * eps)
         assert abs(fd - g[0, i].item()) <= 1e-5 * max(1e-3, abs(fd)) + 1e-9
+
+
+# ----------------------------------------------------------------------------- known answers built outside dicp_ref
+import pytest  # noqa: E402
+
+import dicp_kat as kat  # noqa: E402
+
+
+def _run_ref(icp_type, src, tgt, T0, dim, K, loss=None, trim=50.0, weight=None, tol=1e-12):
+    ref = dicp_ref.ICPRef(icp_type, differentiable=False, max_iterations=K, tolerance=tol)
+    lf = None if loss is None else {"name": loss, "metric": 1.0}
+    w = None if weight is None else torch.from_numpy(np.asarray(weight, np.float32))[None]
+    return ref.icp(torch.from_numpy(src)[None], torch.from_numpy(tgt)[None], T_init=torch.from_numpy(np.asarray(T0, np.float32))[None],
+                   weight=w, trim_dist=trim, loss_fn=lf, dim=dim)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("icp_type", ["pt2pt", "pt2pl"])
+def test_kat_noise_free_copy_recovers_transform(icp_type, dim):
+    """Noise-free copy clouds, offset inside the reference's perturbation envelope: the transform is recovered
+    to north_star's gate, 1e-3 m / 1e-4 rad (in fact to fp32 rounding of the clouds)."""
+    src, tgt, T_true = kat.jittered_grid_pair(dim, seed=3 + dim)
+    out = _run_ref(icp_type, src, tgt, np.eye(4), dim, K=30)
+    dt, da = kat.pose_errors(out["T"][0].numpy(), T_true, dim)
+    assert dt <= 1e-3 and da <= 1e-4, (dt, da)
+    assert dt <= 2e-5 and da <= 2e-6, (dt, da)
+
+
+@pytest.mark.parametrize("icp_type,dim,loss", [("pt2pt", 2, None), ("pt2pl", 2, "huber"), ("pt2pt", 3, "cauchy"), ("pt2pl", 3, None),
+                                               ("pt2pl", 2, "cauchy"), ("pt2pt", 2, "huber")])
+def test_kat_one_gauss_newton_step_from_definitions(icp_type, dim, loss):
+    """One iteration against a step computed from the definitions (finite-difference Jacobian of scipy's
+    matrix exponential, exhaustive argmin, numpy solve): independent of dicp_ref's closed forms."""
+    src, tgt, _ = kat.jittered_grid_pair(dim, seed=11)
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.2, 1.0, len(src)).astype(np.float32)
+    T0 = kat.exp_se3([0.3, -0.2, 0.1 if dim == 3 else 0, 0.01 if dim == 3 else 0, 0, 0.03]).astype(np.float32)
+    T1, delta, idx = kat.gauss_newton_step(src, tgt, T0, w, icp_type, dim, loss=loss, k=1.0, trim=5.0)
+    out = _run_ref(icp_type, src, tgt, T0, dim, K=1, loss=loss, trim=5.0, weight=w)
+    assert np.array_equal(out["hist"]["idx"][0][0].numpy(), idx)
+    got = out["hist"]["delta"][0][0].numpy()
+    np.testing.assert_allclose(got, delta, rtol=2e-5, atol=2e-6)          # fp32 per-point terms vs fp64
+    np.testing.assert_allclose(out["T"][0].numpy(), T1, atol=3e-6)
+
+
+@pytest.mark.parametrize("r2,loss", [(1.0 - 1e-3, "huber"), (1.0, "huber"), (1.0 + 1e-3, "huber"), (3.0, "huber"),
+                                     (0.7, "cauchy"), (2.0, None)])
+def test_kat_huber_kink_closed_form(r2, loss):
+    """Robust weights at and around the Huber kink r = k: the first step of the two-group line problem has
+    the closed form of dicp_kat.two_group_delta_y."""
+    src, tgt, (n1, n2, r1) = kat.two_group_lines(r2)
+    out = _run_ref("pt2pl", src, tgt, np.eye(4), 2, K=1, loss=loss, trim=5.0)
+    d = out["hist"]["delta"][0][0].numpy()
+    want = kat.two_group_delta_y(r2, n1, n2, r1, loss, 1.0, 5.0)
+    assert abs(d[1] - want) <= 2e-7 * max(1.0, abs(want)) and abs(d[0]) < 1e-9 and abs(d[2]) < 1e-9
+    if loss == "huber" and r2 > 1.0:       # the kink moved the answer (a plain least-squares step differs)
+        assert abs(want - kat.two_group_delta_y(r2, n1, n2, r1, None, 1.0, 5.0)) > 1e-4
+
+
+@pytest.mark.parametrize("r2,kept", [(5.0 - 1e-3, True), (5.0, False), (5.0 + 1e-3, False)])
+def test_kat_trim_boundary_closed_form(r2, kept):
+    """Hard trim gate d < trim_dist (5.0 at icp_weight_policy.py:279): a correspondence at exactly the trim
+    distance is dropped, one just inside is kept."""
+    src, tgt, (n1, n2, r1) = kat.two_group_lines(r2)
+    out = _run_ref("pt2pl", src, tgt, np.eye(4), 2, K=1, loss=None, trim=5.0)
+    d = out["hist"]["delta"][0][0].numpy()
+    want = kat.two_group_delta_y(r2, n1, n2, r1, None, 1.0, 5.0)
+    assert abs(d[1] - want) <= 2e-7 * max(1.0, abs(want))
+    assert (abs(want - r1) < 1e-7) == (not kept)
