@@ -34,12 +34,11 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
         T, mask, nn0 = model(batch["loc_data"], batch["map_data"], raw["T_init"])
         if backward:
             mask.retain_grad()
+            idx_hip = T.grad_fn.saved_tensors[3].cpu().numpy()          # (K,B,N) per-iteration correspondences
             loss, _ = trn.eval_training_loss(T, mask, nn0, raw["T_gt"], batch["loc_data"], batch["map_data"], model,
                                              loss_weights=lw)
             loss.backward()
-    if backward:
-        idx_hip = T.grad_fn.saved_tensors[3].cpu().numpy()              # (K,B,N) per-iteration correspondences
-    else:
+    if not backward:
         idx_hip = model.ICP_alg.last_state["idx"].cpu().numpy()         # (1,B,N): the last iteration
     # ---------------- oracle, its own fp32 mask
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
@@ -79,6 +78,16 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     res["loss_rel_err"] = abs(float(loss) - float(loss_d)) / max(1.0, abs(float(loss_d)))
     gm, gm_ref = mask.grad.cpu().numpy(), mh.grad.numpy()
     res["mask_grad_rel"] = float(np.abs(gm - gm_ref).max() / np.abs(gm_ref).max())
+    # The maximum above is set by ONE pixel per image: the normalised mask is exactly 1 at its arg-max
+    # (icp_weight_policy.py:192-193) and BCELoss's gradient there is 1 / (eps = 1e-12) / N, ~1e5.  The part that
+    # comes through the dICP backward lives on the pixels the scan points sample; judge it on those pixels
+    # alone, against their own scale.
+    from oracle import radar_ref
+    taps = radar_ref.extract_weights_grad_mask(tuple(mh.shape), cb["raw_pc"].numpy(),
+                                               np.ones(cb["raw_pc"].shape[:2], np.float32)) != 0
+    sel = taps & (mh.detach().numpy() < 1.0)
+    res["mask_grad_rel_taps"] = float(np.abs(gm - gm_ref)[sel].max() / np.abs(gm_ref)[sel].max())
+    res["mask_grad_taps_scale"] = float(np.abs(gm_ref)[sel].max())
     # ---------------- oracle end to end (fp32 network): the bf16 budget of the parameter gradients
     w2 = train_ref.gather_weights(mask_ref, cb["raw_pc"])
     out2 = ref.icp.icp(cb["filtered_pc"], cb["map_pc"], T_init=cb["T_init"], weight=w2, trim_dist=5.0, loss_fn=loss_fn, dim=2)

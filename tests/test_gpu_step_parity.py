@@ -52,6 +52,6 @@ def test_config2_b32_full_step_parity():
     assert res["idx_mismatches"] == 0 and res["icp_iters"] == 10, res
     assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
     assert res["loss_rel_err"] < 1e-4, res
-    assert res["mask_grad_rel"] <= 2e-3, res
-    # parameter gradients, bf16 storage vs fp32 (stated budget)
-    assert res["param_grad_rel"] < 0.15 and res["param_grad_cos_min"] > 0.85, res
+    assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
+    # parameter gradients, bf16 storage vs fp32 (stated budget; measured 0.036 / 0.979: DESIGN.md §5b)
+    assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
