@@ -310,6 +310,42 @@ int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, c
                              float scale, float leaky_slope, float *part, float *coef, void *gx, float *dW,
                              float *db, void *stream);
 
+/* ------------------------------------------------------------------ the mask U-Net as two calls
+ * mmk_unet_forward replaces the network part of LearnICPWeightPolicy.forward
+ * (mm_masking/icp_weight_policy.py:161-199: encoder, twice-applied decoder blocks, 1x1 + sigmoid, amax
+ * normalisation) and mmk_unet_backward its autograd (train_icp_weights.py:51), sequencing the building
+ * blocks above from the host side of the ABI: ~290 launches per training step without a Python call each.
+ * Results are bit-identical to issuing the same building blocks one by one (tests/test_gpu_unet_driver.py). */
+typedef struct {
+    int32_t B, H, W, cin;       /* network input: fp32 NCHW (B,cin,H,W), cin = 1..4, H, W >= 32          */
+    const float *x;
+    const float *pre;           /* (cin,2) offset / reciprocal scale from mmk_channel_minmax, or NULL     */
+    const float *const *params; /* HOST array of 46 device pointers in state_dict order: weight, bias of
+                                   encoder.{0..5}.{0,2}, decoder.{0..4}.{0,2}, final_layer.0 (fp32 masters) */
+    float drop_p;               /* dropout probability of this pass (0 in eval mode)                      */
+    uint32_t seed;              /* dropout stream of this pass                                            */
+    float leaky_slope;          /* 0 = ReLU, else nn.LeakyReLU(slope) (params["leaky"])                    */
+    int32_t norm;               /* 1: mask / amax(mask) per image (params["norm_weights"])                */
+    void *workspace;            /* mmk_unet_workspace_bytes(): packed weights + every activation; written by
+                                   the forward, read by the backward -- the caller keeps it in between     */
+    size_t workspace_bytes;
+    float *mask;                /* (B,H,W) fp32: output of the forward, input of the backward             */
+} mmk_unet_desc;
+
+size_t mmk_unet_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t cin);
+/* scratch of the backward pass (gradient tensors, partial sums); needs a HIP device (occupancy queries) */
+size_t mmk_unet_scratch_bytes(int32_t B, int32_t H, int32_t W, int32_t cin);
+int mmk_unet_forward(const mmk_unet_desc *d, void *stream);
+/* gmask (B,H,W) fp32 = dL/dmask; grads: HOST array of 46 device pointers, same order and shapes as params,
+ * overwritten with dL/dparam. */
+int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch,
+                      size_t scratch_bytes, void *stream);
+/* Where an activation lives inside the workspace (tests / diagnostics): id 0..5 first conv output of encoder
+ * block i, 6..11 second (post-dropout) output, 12..17 t[i] (block output after pooling), 18 + 5 j + {0..4}:
+ * decoder block j's up-sampled input, a1, d1, a2, d2.  NHWC bf16 (B,h,w,c) at byte `offset`. */
+int mmk_unet_tensor(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t id, size_t *offset, int32_t *h,
+                    int32_t *w, int32_t *c);
+
 #ifdef __cplusplus
 }
 #endif

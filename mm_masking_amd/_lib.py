@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SO_PATH = os.environ.get("MMK_LIB", os.path.join(_HERE, "libmmk_hip.so"))   # MMK_LIB: A/B another build (development)
-SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip"]
+SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip", "mmk_unet_driver.hip"]
 
 _lib = None
 
@@ -49,6 +49,14 @@ class ConvDesc(ctypes.Structure):
                 ("accumulate2", ctypes.c_int32), ("scale2", ctypes.c_float),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32),
                 ("leaky_slope", ctypes.c_float), ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p)]
+
+
+class UNetDesc(ctypes.Structure):
+    """mmk_unet_desc of include/mmk.h."""
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("cin", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("pre", ctypes.c_void_p), ("params", ctypes.POINTER(ctypes.c_void_p)),
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("leaky_slope", ctypes.c_float), ("norm", ctypes.c_int32),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("mask", ctypes.c_void_p)]
 
 
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
@@ -111,6 +119,12 @@ def _declare(lib):
         "mmk_mask_normalize": (ctypes.c_int, [c_vp, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, f32, c_vp, c_vp,
                                                     c_vp, c_vp, c_vp, c_vp]),
+        "mmk_unet_workspace_bytes": (sz, [i32, i32, i32, i32]),
+        "mmk_unet_scratch_bytes": (sz, [i32, i32, i32, i32]),
+        "mmk_unet_forward": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp]),
+        "mmk_unet_backward": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp, ctypes.POINTER(ctypes.c_void_p), c_vp, sz, c_vp]),
+        "mmk_unet_tensor": (ctypes.c_int, [i32, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                           ctypes.POINTER(i32)]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),
         "mmk_extract_peaks_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_extract_peaks": (ctypes.c_int, [c_vp, i32, i32, i32, f32, c_vp, c_vp, c_vp, i32, f32, i32, c_vp, c_vp,

@@ -6,6 +6,7 @@ default network configuration (ReLU, no batch norm; mm_masking/icp_weight_policy
 compatibility); every step packs them to bf16 MFMA-fragment order on the device.
 """
 import ctypes
+import os
 
 import torch
 
@@ -475,8 +476,84 @@ class _UNet(torch.autograd.Function):
         return (None, None, None, None, None, None, None) + tuple(out)
 
 
-def unet_mask(module, x, training, seed, norm=False, pre=None, slope=0.0):
+# ----------------------------------------------------------------------------- the network as two C-ABI calls
+DRIVER = os.environ.get("MMK_UNET_DRIVER", "native")     # "native": mmk_unet_forward / _backward (csrc/mmk_unet_driver.hip);
+#                                                          "python": the launch-by-launch schedule of _UNet above (the same
+#                                                          kernels in the same order: bit-identical results; tests, diagnostics)
+
+
+def workspace_tensor(ws, B, H, W, cin, tid):
+    """View of one activation inside a native-driver workspace (include/mmk.h: mmk_unet_tensor ids)."""
+    off, h, w, c = ctypes.c_size_t(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(_lib.lib().mmk_unet_tensor(B, H, W, cin, tid, ctypes.byref(off), ctypes.byref(h), ctypes.byref(w), ctypes.byref(c)))
+    n = B * h.value * w.value * c.value
+    return ws[off.value:off.value + 2 * n].view(BF16).view(B, h.value, w.value, c.value)
+
+
+class _UNetNative(torch.autograd.Function):
+    """The same network through mmk_unet_forward / mmk_unet_backward: one C call per pass."""
+
+    @staticmethod
+    def forward(ctx, x, pre, drop_p, seed, training, norm, slope, *params):
+        L = _lib.lib()
+        dev = x.device
+        x = x.contiguous().float()
+        B, cin, H, W = x.shape
+        P = [p.detach().float().contiguous() for p in params]
+        nbytes = L.mmk_unet_workspace_bytes(B, H, W, cin)
+        if nbytes == 0:
+            raise _lib.MmkError("libmmk_hip: %s" % L.mmk_last_error().decode(errors="replace"))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mask = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+        pp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in P])
+        d = _lib.UNetDesc(B=B, H=H, W=W, cin=cin, x=x.data_ptr(), pre=None if pre is None else pre.data_ptr(), params=pp,
+                          drop_p=float(drop_p) if training else 0.0, seed=int(seed) & 0xFFFFFFFF, leaky_slope=float(slope),
+                          norm=1 if norm else 0, workspace=ws.data_ptr(), workspace_bytes=nbytes, mask=mask.data_ptr())
+        _lib.check(L.mmk_unet_forward(ctypes.byref(d), _sp(dev)))
+        if DEBUG is not None:
+            def tv(tid):
+                return workspace_tensor(ws, B, H, W, cin, tid)
+            DEBUG["fwd"] = {"t": [tv(12 + i) for i in range(6)],
+                            "enc": {"e%d" % i: (tv(i), tv(6 + i)) for i in range(6)},
+                            "dec": [tuple(tv(18 + 5 * j + q) for q in range(5)) for j in range(5)]}
+        ctx.desc_args = (B, H, W, cin, float(drop_p) if training else 0.0, int(seed) & 0xFFFFFFFF, float(slope), 1 if norm else 0)
+        ctx.x, ctx.pre, ctx.P, ctx.ws = x, pre, P, ws
+        # an alias, not the output object itself (output -> grad_fn -> ctx -> output would be a reference cycle
+        # that keeps the workspace alive until the cyclic GC runs)
+        ctx.mask = mask.detach()
+        return mask
+
+    @staticmethod
+    def backward(ctx, gmask):
+        L = _lib.lib()
+        B, H, W, cin, p_drop, seed, slope, norm = ctx.desc_args
+        x, P, ws = ctx.x, ctx.P, ctx.ws
+        dev = x.device
+        gmask = gmask.contiguous().float()
+        nscratch = L.mmk_unet_scratch_bytes(B, H, W, cin)
+        if nscratch == 0:
+            raise _lib.MmkError("libmmk_hip: %s" % L.mmk_last_error().decode(errors="replace"))
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev)
+        sizes = [p.numel() for p in P]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)
+        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+        grads = [flat[offs[i]:offs[i] + sizes[i]].view(P[i].shape) for i in range(len(P))]
+        pp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in P])
+        gp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in grads])
+        d = _lib.UNetDesc(B=B, H=H, W=W, cin=cin, x=x.data_ptr(), pre=None if ctx.pre is None else ctx.pre.data_ptr(), params=pp,
+                          drop_p=p_drop, seed=seed, leaky_slope=slope, norm=norm, workspace=ws.data_ptr(),
+                          workspace_bytes=ws.numel(), mask=ctx.mask.data_ptr())
+        _lib.check(L.mmk_unet_backward(ctypes.byref(d), _p(gmask), gp, _p(scratch), nscratch, _sp(dev)))
+        ctx.ws = None
+        return (None, None, None, None, None, None, None) + tuple(grads)
+
+
+def unet_mask(module, x, training, seed, norm=False, pre=None, slope=0.0, driver=None):
     """sigmoid mask (B,H,W) fp32 of the module's network on fp32 NCHW input x; ``norm``: divided by its
     per-image maximum (the policy's ``norm_weights``), inside the same autograd node; ``pre`` (C,2): the
-    input is (x - pre[c,0]) * pre[c,1], applied by the first layer while it loads x."""
-    return _UNet.apply(x, pre, float(module.dropout), int(seed), bool(training), bool(norm), float(slope), *param_list(module))
+    input is (x - pre[c,0]) * pre[c,1], applied by the first layer while it loads x; ``slope`` > 0: the
+    LeakyReLU network.  ``driver``: "native" (default, one C call per pass) or "python" (launch by launch)."""
+    fn = _UNetNative if (driver or DRIVER) == "native" else _UNet
+    return fn.apply(x, pre, float(module.dropout), int(seed), bool(training), bool(norm), float(slope), *param_list(module))
