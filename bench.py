@@ -348,6 +348,9 @@ def main():
         dt = float(tmax.item())
 
     progress("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
+    if len(nn_ms) == args.steps * ICP_ITERS:
+        by_it = nn_ms.reshape(args.steps, ICP_ITERS).mean(axis=0) * 1e3
+        progress("NN launch us by ICP iteration: " + " ".join("%.0f" % v for v in by_it))
     result = None
     if rank == 0:
         nn_avg_s = float(nn_ms.mean()) * 1e-3 if len(nn_ms) else float("nan")

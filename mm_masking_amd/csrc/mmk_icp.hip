@@ -199,6 +199,217 @@ __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// I2 with an exact pre-filter (the default brute-force engine).  The scan above spends 4.5 vector
+// lane-operations per (point, target) pair on d = fma(dy, dy, dx * dx) and the fp32 VALU is what bounds it
+// (DESIGN.md §5).  Here every pair is first priced with the expanded form
+//      e_j = fma(tx_j, a, fma(ty_j, b, tn_j)),   a = -2 px, b = -2 py,  tn_j = |t_j|^2 (one plane more, packed
+//      once per icp() call)                      -> 2 lane-operations (+ 1/2 for the running minimum)
+// which equals D_j - |p|^2 up to rounding, D_j the true squared distance.  Still exhaustive: every target is
+// visited by every point; only targets that can be the argmin are evaluated with the normative formula.
+//
+// Exactness.  u = 2^-24.  The normative value obeys |d_j - D_j| <= 5u D_j (four relative roundings).  For a
+// target with |t_j| <= |p| + sqrt(D_j):  |e_j - (D_j - |p|^2)| <= G(D_j), G(D) = u (7.1 |p|^2 + 10.1 |p| sqrt(D) +
+// 5.1 D)  [tn: 2 roundings; each fma one rounding of a partial sum bounded by |t|^2 + 2 |p||t|].  Let j* be the
+// normative argmin and m the argmin of e, X = D_m.  d_j* <= d_k for all k gives D_j* <= X (1 + 11u), hence
+//      e_j* - e_m <= 11u X + G(X (1 + 11u)) + G(X) <= u (24.3 |p|^2 + 31.4 X),   X <= (e_m + |p|^2)(1 + 13u).
+// So j* lies among the targets with e_j <= thr(e_m), thr(b) = b + kappa (|p|^2 + max(0, b + |p|^2)), kappa = 48u
+// (dim 2; 64u for dim 3 where the same derivation gives u (38 |p|^2 + 41 X)): the constants leave > 30 % of slack
+// for the fp32 evaluation of thr itself.  thr is monotone in b, so testing a chunk of 32 targets against the
+// RUNNING minimum b_run >= e_m flags a superset of the chunks that hold such a target; the flagged chunks (one
+// bit each) are then re-scanned with nn_dist() -- from the LDS tile, before the next tile is staged -- in ascending
+// order with a strict '<', which yields exactly the lowest-index argmin of the oracle (oracle/nn_search.c):
+// tests/test_gpu_icp.py::test_nn_bit_exact.  b_run starts from e of the previous iteration's correspondent (any
+// e_j bounds the minimum), so after the first iteration little more than the chunks that matter is flagged.
+// Work decomposition, XCD mapping and the 64-bit atomic-min merge of the target ranges are those of the scan above.
+constexpr int PF_CH = 32;            // targets per flag bit (32 chunks per LDS tile: one flag word per point and tile)
+
+template <int DIM>
+__global__ void pack_norm_kernel(const float *__restrict__ tgtp, int Mpad, float *__restrict__ tnorm)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= Mpad) return;
+    const float *tb = tgtp + (size_t)b * DIM * Mpad;
+    const float tx = tb[j], ty = tb[(size_t)Mpad + j];
+    float n = __builtin_fmaf(ty, ty, tx * tx);
+    if constexpr (DIM == 3) {
+        const float tz = tb[(size_t)2 * Mpad + j];
+        n = __builtin_fmaf(tz, tz, n);
+    }
+    tnorm[(size_t)b * Mpad + j] = n;
+}
+
+template <int DIM, int P>
+__global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ tnorm,
+    const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx, int B,
+    int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
+    unsigned long long *__restrict__ packed)
+{
+    __shared__ __attribute__((aligned(16))) float lt[DIM + 1][NN_TILE];
+    const int tid = threadIdx.x;
+    const int ntiles = Mpad / NN_TILE;
+
+    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+        const int xcd = u & 7;
+        int rest = u >> 3;
+        const int tu = rest % ntu;
+        rest /= ntu;
+        const int sb = rest % nsb;
+        const int b = (rest / nsb) * 8 + xcd;
+        if (b >= B) continue;
+        if (active != nullptr && active[b] == 0) continue;
+
+        float T[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
+        const float *tb = tgtp + (size_t)b * DIM * Mpad;
+        const float *tnb = tnorm + (size_t)b * Mpad;
+
+        float p[P][DIM], a[P][DIM], pn[P], brun[P], cur[P];
+        int pidx[P], jj[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int i = sb * (NN_THREADS * P) + q * NN_THREADS + tid;
+            pidx[q] = i;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            if (i < N) {
+                const float *sp = src + ((size_t)b * N + i) * 3;
+                s0 = sp[0];
+                s1 = sp[1];
+                s2 = sp[2];
+            }
+            const float s[3] = {s0, s1, s2};
+            transform_point<DIM>(T, s, p[q]);
+            float n2 = p[q][0] * p[q][0] + p[q][1] * p[q][1];
+            if constexpr (DIM == 3) n2 += p[q][2] * p[q][2];
+            pn[q] = n2;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) a[q][c] = -2.0f * p[q][c];
+            // Any e_j is an upper bound of the minimum: start from the target this point was matched with in the
+            // previous iteration (the pose moves little between iterations), so that from the second iteration
+            // on hardly any chunk but the ones that matter is flagged.  Same fma chain as in the scan below.
+            float b0 = INFINITY;
+            if (prev_idx != nullptr && i < N) {
+                const int j = prev_idx[(size_t)b * N + i];
+                if (j >= 0 && j < Mpad) {
+                    float e = __builtin_fmaf(tb[(size_t)Mpad + j], a[q][1], tnb[j]);
+                    if constexpr (DIM == 3) e = __builtin_fmaf(tb[(size_t)2 * Mpad + j], a[q][2], e);
+                    b0 = __builtin_fmaf(tb[j], a[q][0], e);
+                    b0 = (b0 == b0) ? b0 : INFINITY;
+                }
+            }
+            brun[q] = b0;
+            cur[q] = INFINITY;
+        }
+
+        const int t0 = tu * tiles_per_unit;
+        const int t1 = min(ntiles, t0 + tiles_per_unit);
+#pragma unroll
+        for (int q = 0; q < P; ++q) jj[q] = t0 * NN_TILE;
+
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < DIM; ++c)
+                *reinterpret_cast<float4 *>(&lt[c][tid * 4]) =
+                    *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
+            *reinterpret_cast<float4 *>(&lt[DIM][tid * 4]) = *reinterpret_cast<const float4 *>(tnb + (size_t)t * NN_TILE + tid * 4);
+            __syncthreads();
+            unsigned w[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) w[q] = 0u;
+#pragma unroll 2
+            for (int c = 0; c < NN_TILE / PF_CH; ++c) {
+                float m[P];
+#pragma unroll
+                for (int hf = 0; hf < PF_CH / 16; ++hf) {
+                    float tx[16], ty[16], tz[16], tn[16];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int o = c * PF_CH + hf * 16 + h * 4;
+                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o]);
+                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o]);
+                        const float4 vn = *reinterpret_cast<const float4 *>(&lt[DIM][o]);
+                        tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
+                        ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
+                        tn[h * 4 + 0] = vn.x; tn[h * 4 + 1] = vn.y; tn[h * 4 + 2] = vn.z; tn[h * 4 + 3] = vn.w;
+                        if constexpr (DIM == 3) {
+                            const float4 vz = *reinterpret_cast<const float4 *>(&lt[2][o]);
+                            tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
+                        } else {
+                            tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        auto ev = [&](int j) -> float {
+                            float e = __builtin_fmaf(ty[j], a[q][1], tn[j]);
+                            if constexpr (DIM == 3) e = __builtin_fmaf(tz[j], a[q][2], e);
+                            return __builtin_fmaf(tx[j], a[q][0], e);
+                        };
+                        float mm = (hf == 0) ? ev(0) : __builtin_fminf(m[q], ev(0));
+#pragma unroll
+                        for (int j = 1; j + 1 < 16; j += 2) mm = __builtin_fminf(__builtin_fminf(mm, ev(j)), ev(j + 1));
+                        m[q] = __builtin_fminf(mm, ev(15));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    brun[q] = __builtin_fminf(brun[q], m[q]);
+                    const float thr = __builtin_fmaf(kappa, pn[q] + __builtin_fmaxf(0.f, brun[q] + pn[q]), brun[q]);
+                    w[q] |= (m[q] <= thr) ? (1u << c) : 0u;
+                }
+            }
+            // ---- exact re-scan of this tile's flagged chunks while the tile is in LDS (chunks ascending, tiles
+            // ascending, strict '<': the lowest index among equal distances)
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                unsigned ww = w[q];
+                while (__any(ww != 0u)) {
+                    if (ww != 0u) {
+                        const int c = __ffs((int)ww) - 1;
+                        ww &= ww - 1u;
+                        const int o0 = c * PF_CH;
+                        float best = INFINITY;
+                        int bj = 0;
+#pragma unroll
+                        for (int h = 0; h < PF_CH / 4; ++h) {
+                            const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
+                            const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
+                            float4 vz = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if constexpr (DIM == 3) vz = *reinterpret_cast<const float4 *>(&lt[2][o0 + h * 4]);
+                            const float d0 = nn_dist<DIM>(vx.x, vy.x, vz.x, p[q]), d1 = nn_dist<DIM>(vx.y, vy.y, vz.y, p[q]);
+                            const float d2 = nn_dist<DIM>(vx.z, vy.z, vz.z, p[q]), d3 = nn_dist<DIM>(vx.w, vy.w, vz.w, p[q]);
+                            if (d0 < best) { best = d0; bj = h * 4 + 0; }
+                            if (d1 < best) { best = d1; bj = h * 4 + 1; }
+                            if (d2 < best) { best = d2; bj = h * 4 + 2; }
+                            if (d3 < best) { best = d3; bj = h * 4 + 3; }
+                        }
+                        if (best < cur[q]) {
+                            cur[q] = best;
+                            jj[q] = t * NN_TILE + o0 + bj;
+                        }
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int i = pidx[q];
+            if (i >= N) continue;
+            // (a range that holds no candidate below the starting bound has nothing to add; range 0 always writes, so
+            // that a point whose coordinates are not finite still ends with the oracle's (inf, 0))
+            if (!(cur[q] < INFINITY) && tu != 0) continue;
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(cur[q]) << 32) | (unsigned long long)(unsigned)jj[q];
+            atomicMin(&packed[(size_t)b * N + i], key);
+        }
+    }
+}
+
 constexpr unsigned long long NN_KEY_INIT = ~0ull;
 
 __global__ void nn_unpack_kernel(const unsigned long long *__restrict__ packed, int n, int32_t *__restrict__ idx,
@@ -972,12 +1183,26 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
     int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P;
+    bool prefilter;
 };
+
+// MMK_NN_PREFILTER=0 selects the plain scan (nn_search_kernel) instead of the pre-filtered one: same results,
+// A/B measurements (scripts/bench_nn.py)
+bool use_nn_prefilter()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_NN_PREFILTER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 // Tuning knobs of the NN kernel; MMK_NN_VARIANT = "<chunk>,<P>,<tiles_per_unit>" overrides
 // them for experiments (scripts/bench_nn.py).
 struct NNTune {
     int chunk = 16, P = 2, tiles_per_unit = 5;
+    bool user = false;
     NNTune()
     {
         if (const char *e = getenv("MMK_NN_VARIANT")) {
@@ -986,6 +1211,7 @@ struct NNTune {
                 chunk = c;
                 P = p;
                 tiles_per_unit = t;
+                user = true;
             }
         }
     }
@@ -1000,7 +1226,11 @@ NNPlan nn_plan(int B, int N, int M)
     pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
-    pl.tiles_per_unit = std::min(tune.tiles_per_unit, pl.ntiles);
+    pl.prefilter = use_nn_prefilter() && (pl.P == 2 || pl.P == 4);
+    // (pre-filtered scan: ranges of 2 tiles -- 3 200 units at the bench shape instead of 1 280 -- balance the CUs better,
+    // and a range without candidates below the starting bound costs no atomic: 224 -> 216 us per launch)
+    pl.tiles_per_unit = std::min((pl.prefilter && !tune.user) ? 2 : tune.tiles_per_unit, pl.ntiles);
+
     pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
     pl.total_units = Bpad * pl.nsb * pl.ntu;
@@ -1027,11 +1257,26 @@ void launch_nn_t(const float *src, const float *tgtp, const float *Tk, const int
 }
 
 // `packed` (B,N) must hold NN_KEY_INIT on entry (memset 0xFF or re-armed by the accumulate kernel).
-int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
-              const NNPlan &pl, unsigned long long *packed, hipStream_t st)
+int launch_nn(int dim, const float *src, const float *tgtp, const float *tnorm, const float *Tk, const int32_t *active,
+              const int32_t *prev_idx, int B, int N, const NNPlan &pl, unsigned long long *packed, hipStream_t st)
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    if (pl.prefilter) {
+        constexpr float U = 5.9604645e-8f;       // 2^-24
+#define MMK_PF_CASE(D, PP, KAPPA)                                                                                          \
+    if (dim == D && pl.P == PP)                                                                                          \
+        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, tnorm, Tk, active, \
+                           prev_idx, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
+        MMK_PF_CASE(2, 2, 48.0f); MMK_PF_CASE(2, 4, 48.0f); MMK_PF_CASE(3, 2, 64.0f); MMK_PF_CASE(3, 4, 64.0f);
+#undef MMK_PF_CASE
+        MMK_LAUNCH_CHECK();
+        if (rec) {
+            MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+            g_prof.n++;
+        }
+        return MMK_OK;
+    }
 #define MMK_NN_CASE(D, C, PP) \
     if (dim == D && pl.chunk == C && pl.P == PP) launch_nn_t<D, C, PP>(src, tgtp, Tk, active, B, N, pl, packed, st)
     MMK_NN_CASE(2, 8, 1); MMK_NN_CASE(2, 8, 2); MMK_NN_CASE(2, 8, 4);
@@ -1044,6 +1289,16 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
         MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
         g_prof.n++;
     }
+    return MMK_OK;
+}
+
+int pack_norm(int dim, const float *tgtp, int B, int Mpad, float *tnorm, hipStream_t st)
+{
+    if (dim == 2)
+        hipLaunchKernelGGL(pack_norm_kernel<2>, dim3(Mpad / 256, B), dim3(256), 0, st, tgtp, Mpad, tnorm);
+    else
+        hipLaunchKernelGGL(pack_norm_kernel<3>, dim3(Mpad / 256, B), dim3(256), 0, st, tgtp, Mpad, tnorm);
+    MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
 
@@ -1064,6 +1319,7 @@ int check_params(const mmk_icp_params *p)
 
 struct IcpWs {
     float *tgtp;
+    float *tnorm;                // (B,Mpad) |t|^2 of the planar target (pre-filtered scan)
     unsigned long long *packed;  // (B,N) NN keys
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
@@ -1081,6 +1337,7 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     mmk::Arena ar(ws, cap);
     IcpWs w;
     w.tgtp = ar.take<float>((size_t)p->B * p->dim * pl.Mpad);
+    w.tnorm = ar.take<float>((size_t)p->B * pl.Mpad);
     w.packed = ar.take<unsigned long long>((size_t)p->B * p->N);
     w.partials = ar.take<double>((size_t)p->B * nblk * 27);
     w.G0 = ar.take<double>((size_t)p->B * 16);
@@ -1138,7 +1395,9 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
                 g_prof.n++;
             }
         } else {
-            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, B, N, pl, w.packed, st);
+            // the correspondences of the previous iteration (still in the index buffer) start the filter's bound
+            const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
+            int rc = launch_nn(DIM, src, w.tgtp, w.tnorm, Tk, act, prev, B, N, pl, w.packed, st);
             if (rc != MMK_OK) return rc;
         }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
@@ -1227,7 +1486,8 @@ extern "C" size_t mmk_nn_workspace_bytes(int32_t B, int32_t N, int32_t M, int32_
 {
     (void)dim;
     if (B < 1 || N < 1 || M < 1) return 0;
-    return mmk::align_up((size_t)B * N * sizeof(unsigned long long), 256) + 256;
+    return mmk::align_up((size_t)B * N * sizeof(unsigned long long), 256) +
+           mmk::align_up((size_t)B * mmk_nn_padded_m(M) * sizeof(float), 256) + 512;
 }
 
 extern "C" int mmk_nn_search(const float *source, const float *target_planar, const float *T, int32_t B, int32_t N,
@@ -1240,13 +1500,16 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     const NNPlan pl = nn_plan(B, N, M);
     mmk::Arena ar(workspace, workspace_bytes);
     unsigned long long *packed = ar.take<unsigned long long>((size_t)B * N);
+    float *tnorm = ar.take<float>((size_t)B * pl.Mpad);
     if (!ar.ok() || workspace == nullptr) {
         mmk::set_error("mmk_nn_search: workspace too small (%zu < %zu)", workspace_bytes, ar.off);
         return MMK_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     MMK_CHECK_HIP(hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
-    int rc = launch_nn(dim, source, target_planar, T, nullptr, B, N, pl, packed, st);
+    int rc = pack_norm(dim, target_planar, B, pl.Mpad, tnorm, st);
+    if (rc != MMK_OK) return rc;
+    rc = launch_nn(dim, source, target_planar, tnorm, T, nullptr, nullptr, B, N, pl, packed, st);
     if (rc != MMK_OK) return rc;
     hipLaunchKernelGGL(nn_unpack_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, packed, B * N, idx, d2);
     MMK_LAUNCH_CHECK();
@@ -1308,6 +1571,10 @@ extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, con
     const int B = p->B;
     rc = mmk_pack_target(target, B, p->M, p->tgt_cols, p->dim, w.tgtp, stream);
     if (rc != MMK_OK) return rc;
+    if (p->nn_method == MMK_NN_BRUTE) {
+        rc = pack_norm(p->dim, w.tgtp, B, mmk_nn_padded_m(p->M), w.tnorm, st);
+        if (rc != MMK_OK) return rc;
+    }
     MMK_CHECK_HIP(hipMemcpyAsync(T_hist, T_init, sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, active_hist, B, 1);
     MMK_LAUNCH_CHECK();

@@ -49,7 +49,7 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     ref.sd = sd
     x = unet_ref.assemble_input(cb["fft_data"])
     with torch.set_grad_enabled(backward):
-        mask_ref = unet_ref.unet_mask(x, sd, dropout_p=0.0, training=True)
+        mask_ref = unet_ref.unet_mask(x, sd, norm_weights=bool(params.get("norm_weights", True)), dropout_p=0.0, training=True)
     res["mask_max_abs"] = float((mask.detach().cpu() - mask_ref.detach()).abs().max())
     # ---------------- oracle downstream of the HIP mask
     mh = mask.detach().cpu().clone().requires_grad_(backward)
@@ -97,7 +97,8 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     num = sum(float(((gp[k].grad.cpu() - sd[k].grad) ** 2).sum()) for k in sd)
     den = sum(float((sd[k].grad ** 2).sum()) for k in sd)
     res["param_grad_rel"] = (num / den) ** 0.5
-    cos = {k: float(torch.nn.functional.cosine_similarity(gp[k].grad.cpu().flatten(), sd[k].grad.flatten(), dim=0)) for k in sd}
+    cos = {k: float(torch.nn.functional.cosine_similarity(gp[k].grad.cpu().flatten(), sd[k].grad.flatten(), dim=0)) for k in sd
+           if sd[k].numel() > 1}            # (a one-element tensor only has a sign)
     kmin = min(cos, key=cos.get)
     res["param_grad_cos_min"] = cos[kmin]
     res["param_grad_cos_min_name"] = kmin

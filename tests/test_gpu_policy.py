@@ -171,18 +171,18 @@ def test_train_step_matches_cpu_port():
     correspondences, pose, loss and mask gradient; parameter gradients within the bf16 budget."""
     import step_parity
     raw, params, batch = _small_batch(B=2, max_pts=2048)
+    # norm_weights off: with it the normalised mask is exactly 1 at its arg-max, BCELoss's gradient there is
+    # ~1e12 / N and cancels against the amax adjoint (icp_weight_policy.py:192-193, train_icp_weights.py:223-226) --
+    # fp32 cancellation noise that swamps the parameter gradients of a 2-image batch in the oracle as in the
+    # product.  The default configuration is compared at the BASELINE batch in test_gpu_step_parity.py.
+    params = dict(params, norm_weights=False)
     res = step_parity.run(raw, params, batch, max_iter=5, seed=1234)
     assert res["mask_max_abs"] < 3e-3, res
     assert res["idx_mismatches"] == 0, res
     assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
     assert res["loss_rel_err"] < 1e-4, res
     assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
-    # With two images the parameter gradients are dominated by fp32 cancellation noise that the reference's own
-    # loss creates: the normalised mask is exactly 1 at its arg-max, BCELoss's gradient there is ~1e12 / N and
-    # cancels against the amax adjoint (icp_weight_policy.py:192-193, train_icp_weights.py:223-226) -- in the
-    # oracle as in the product, with different rounding.  At the BASELINE batch (test_gpu_step_parity.py) the same
-    # comparison gives 0.036 / cosine 0.98.
-    assert res["param_grad_rel"] < 0.35 and res["param_grad_cos_min"] > 0.6, res
+    assert res["param_grad_rel"] < 0.10 and res["param_grad_cos_min"] > 0.9, res
 
 
 def test_training_reduces_loss_bf16():
