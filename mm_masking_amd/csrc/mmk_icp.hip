@@ -240,7 +240,7 @@ __global__ void pack_norm_kernel(const float *__restrict__ tgtp, int Mpad, float
     tnorm[(size_t)b * Mpad + j] = n;
 }
 
-template <int DIM, int P>
+template <int DIM, int P, int SUB>
 __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
     const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ tnorm,
     const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx, int B,
@@ -324,11 +324,11 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
             for (int c = 0; c < NN_TILE / PF_CH; ++c) {
                 float m[P];
 #pragma unroll
-                for (int hf = 0; hf < PF_CH / 16; ++hf) {
-                    float tx[16], ty[16], tz[16], tn[16];
+                for (int hf = 0; hf < PF_CH / SUB; ++hf) {
+                    float tx[SUB], ty[SUB], tz[SUB], tn[SUB];
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int o = c * PF_CH + hf * 16 + h * 4;
+                    for (int h = 0; h < SUB / 4; ++h) {
+                        const int o = c * PF_CH + hf * SUB + h * 4;
                         const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o]);
                         const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o]);
                         const float4 vn = *reinterpret_cast<const float4 *>(&lt[DIM][o]);
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
                         };
                         float mm = (hf == 0) ? ev(0) : __builtin_fminf(m[q], ev(0));
 #pragma unroll
-                        for (int j = 1; j + 1 < 16; j += 2) mm = __builtin_fminf(__builtin_fminf(mm, ev(j)), ev(j + 1));
-                        m[q] = __builtin_fminf(mm, ev(15));
+                        for (int j = 1; j + 1 < SUB; j += 2) mm = __builtin_fminf(__builtin_fminf(mm, ev(j)), ev(j + 1));
+                        m[q] = __builtin_fminf(mm, ev(SUB - 1));
                     }
                 }
 #pragma unroll
@@ -1264,11 +1264,12 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *tnorm, 
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
     if (pl.prefilter) {
         constexpr float U = 5.9604645e-8f;       // 2^-24
-#define MMK_PF_CASE(D, PP, KAPPA)                                                                                          \
-    if (dim == D && pl.P == PP)                                                                                          \
-        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, tnorm, Tk, active, \
+#define MMK_PF_CASE(D, PP, SB, KAPPA)                                                                                     \
+    if (dim == D && pl.P == PP && pl.chunk == SB)                                                                        \
+        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP, SB>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, tnorm, Tk, active, \
                            prev_idx, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
-        MMK_PF_CASE(2, 2, 48.0f); MMK_PF_CASE(2, 4, 48.0f); MMK_PF_CASE(3, 2, 64.0f); MMK_PF_CASE(3, 4, 64.0f);
+        MMK_PF_CASE(2, 2, 16, 48.0f); MMK_PF_CASE(2, 4, 16, 48.0f); MMK_PF_CASE(3, 2, 16, 64.0f); MMK_PF_CASE(3, 4, 16, 64.0f);
+        MMK_PF_CASE(2, 2, 8, 48.0f); MMK_PF_CASE(2, 4, 8, 48.0f); MMK_PF_CASE(3, 2, 8, 64.0f); MMK_PF_CASE(3, 4, 8, 64.0f);
 #undef MMK_PF_CASE
         MMK_LAUNCH_CHECK();
         if (rec) {
