@@ -12,6 +12,7 @@
 //       partial-sum slices of the weight gradients (fp32) | small reduction buffers
 // Nothing is re-used inside a pass: 288 GB of HBM make a bump allocation of ~10 GB at B = 32 the simplest
 // correct choice (no aliasing hazards between the ~290 asynchronous launches).
+#include <stdlib.h>
 #include <string.h>
 
 #include "mmk_common.h"
@@ -186,6 +187,45 @@ int conv(const Plan &p, int h, int w, float slope, const ConvCall &c, void *stre
     return mmk_conv3x3(&d, stream);
 }
 
+// Side stream of the backward pass: the 38 weight-gradient launches are leaves of the dependency graph (inputs:
+// a stored activation and a gradient tensor of the main chain; output: partial sums nobody reads before the final
+// reduction), so they run beside the data-gradient chain instead of inside it -- kernel tails, launch boundaries
+// and the under-filled launches of the 20 x 20 / 40 x 40 levels overlap.  Forked and joined with events, so the
+// caller still sees one stream-ordered call; one side stream per host thread and device, created on first use.
+// MMK_UNET_SIDE_STREAM=0 keeps everything on the caller's stream (same results either way: every weight-gradient
+// slice is written by exactly one launch sequence in program order).
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int dev = -1;
+};
+
+bool use_side_stream()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_UNET_SIDE_STREAM");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+int side_stream(SideStream **out)
+{
+    static thread_local SideStream pool[16];
+    int dev = 0;
+    MMK_CHECK_HIP(hipGetDevice(&dev));
+    SideStream &s = pool[dev & 15];
+    if (s.st == nullptr || s.dev != dev) {
+        MMK_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        MMK_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        MMK_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        s.dev = dev;
+    }
+    *out = &s;
+    return MMK_OK;
+}
+
 // 1/keep as the kernels apply it (mmk_unet.hip: dropout_params)
 float dropout_scale(float p)
 {
@@ -354,8 +394,19 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.part[k]), 0, sizeof(float) * 9 * p.cout[k] * p.cinn[k], st));
             MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.dB[k]), 0, sizeof(float) * p.cout[k], st));
         }
+    SideStream *ss = nullptr;
+    if (use_side_stream()) MMK_TRY(side_stream(&ss));
+    void *wstream = ss ? (void *)ss->st : stream;          // where the weight-gradient launches go
+    if (ss) {       // everything enqueued so far (weight packing, zero fills) precedes the side stream's work
+        MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
+        MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
+    }
     bool part_used[NCONV] = {};
     auto wgrad = [&](int k, const void *x1, int C1, const void *x2, int C2, const void *g, int h, int w) -> int {
+        if (ss) {   // g was produced by the launch just enqueued on the caller's stream
+            MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
+            MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
+        }
         if (p.slices[k] > 0) {
             // (the plan sized the slices for an unsplit input; a split input must give the same count)
             if (mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], C1, B, h, w) != p.slices[k]) {
@@ -363,12 +414,12 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
                 return MMK_ERR_ARG;
             }
             const int rc = mmk_conv3x3_wgrad_partial(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
-                                                     part_used[k] ? 1 : 0, stream);
+                                                     part_used[k] ? 1 : 0, wstream);
             part_used[k] = true;
             return rc;
         }
         return mmk_conv3x3_wgrad(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
-                                 static_cast<float *>(at(sc, p.dB[k])), stream);
+                                 static_cast<float *>(at(sc, p.dB[k])), wstream);
     };
 
     // ---- final layer
@@ -459,10 +510,16 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             slices[k - 1] = p.slices[k]; co[k - 1] = p.cout[k]; ci[k - 1] = p.cinn[k];
             dW[k - 1] = grads[2 * k]; db[k - 1] = grads[2 * k + 1];
         }
-        MMK_TRY(mmk_conv3x3_wgrad_unpack_batch(21, src, slices, co, ci, dW, db, stream));
+        // (on the side stream, behind the last weight-gradient launch: it overlaps the tail of the main chain)
+        MMK_TRY(mmk_conv3x3_wgrad_unpack_batch(21, src, slices, co, ci, dW, db, wstream));
         for (int k = 1; k <= 21; ++k)
             if (p.slices[k] == 0)
-                MMK_CHECK_HIP(hipMemcpyAsync(grads[2 * k + 1], at(sc, p.dB[k]), sizeof(float) * p.cout[k], hipMemcpyDeviceToDevice, st));
+                MMK_CHECK_HIP(hipMemcpyAsync(grads[2 * k + 1], at(sc, p.dB[k]), sizeof(float) * p.cout[k], hipMemcpyDeviceToDevice,
+                                             (hipStream_t)wstream));
+    }
+    if (ss) {       // join: the caller's stream continues only after every gradient is written
+        MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
+        MMK_CHECK_HIP(hipStreamWaitEvent(st, ss->join, 0));
     }
     return MMK_OK;
 }
