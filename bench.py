@@ -331,7 +331,7 @@ def main():
     dt = time.perf_counter() - t0
     per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     progress("per-step GPU ms: " + " ".join("%.1f" % v for v in per_step))
-    progress("host enqueue time %.1f ms/step" % (host_dt / args.steps * 1e3))
+    progress("host time of the enqueue loop %.1f ms/step (with the launch queue full: it mostly waits for the GPU)" % (host_dt / args.steps * 1e3))
     ms1 = torch.cuda.memory_stats(device)
     progress("allocator during the timed region: %d device mallocs, %d frees, %d retries; reserved %.2f GiB" % (
         ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
@@ -347,6 +347,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # host cost of enqueueing one step, measured with an EMPTY launch queue (synchronise, time the Python call, synchronise):
+    # inside the timed loop the host runs ahead until the queue is full and then waits for the GPU, so the loop's host
+    # time says nothing about the host's own cost
+    host_idle = []
+    for i in range(5):
+        torch.cuda.synchronize(device)
+        t_h = time.perf_counter()
+        one_step(args.warmup + args.steps + i)
+        host_idle.append(time.perf_counter() - t_h)
+    torch.cuda.synchronize(device)
+    host_ms = float(np.median(host_idle)) * 1e3
+    progress("host enqueue cost %.1f ms/step (empty queue, median of 5)" % host_ms)
     progress("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     if len(nn_ms) == args.steps * ICP_ITERS:
         by_it = nn_ms.reshape(args.steps, ICP_ITERS).mean(axis=0) * 1e3
@@ -373,7 +385,7 @@ def main():
             "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", "host_enqueue_ms_per_step": host_ms,
             "config": {"workload": ("BASELINE configs[2]: train_icp_weights step fwd+bwd, batch=%d per GPU, 10 dICP "
                                     "iters, point-to-plane Huber, dim=2; 400x3360 polar radar -> GO-CFAR + peaks + "
                                     "polar->Cartesian 640x640 -> U-Net (hand-written NHWC bf16 MFMA kernels, fp32 masters) -> dICP (fp32 points, "
