@@ -203,8 +203,8 @@ __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
 // I2 with an exact pre-filter (the default brute-force engine).  The scan above spends 4.5 vector
 // lane-operations per (point, target) pair on d = fma(dy, dy, dx * dx) and the fp32 VALU is what bounds it
 // (DESIGN.md §5).  Here every pair is first priced with the expanded form
-//      e_j = fma(tx_j, a, fma(ty_j, b, tn_j)),   a = -2 px, b = -2 py,  tn_j = |t_j|^2 (one plane more, packed
-//      once per icp() call)                      -> 2 lane-operations (+ 1/2 for the running minimum)
+//      e_j = fma(tx_j, a, fma(ty_j, b, tn_j)),   a = -2 px, b = -2 py,  tn_j = |t_j|^2 (formed once per target while
+//      its tile is staged into LDS)              -> 2 lane-operations (+ 1/2 for the running minimum)
 // which equals D_j - |p|^2 up to rounding, D_j the true squared distance.  Still exhaustive: every target is
 // visited by every point; only targets that can be the argmin are evaluated with the normative formula.
 //
@@ -224,25 +224,9 @@ __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
 // Work decomposition, XCD mapping and the 64-bit atomic-min merge of the target ranges are those of the scan above.
 constexpr int PF_CH = 32;            // targets per flag bit (32 chunks per LDS tile: one flag word per point and tile)
 
-template <int DIM>
-__global__ void pack_norm_kernel(const float *__restrict__ tgtp, int Mpad, float *__restrict__ tnorm)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (j >= Mpad) return;
-    const float *tb = tgtp + (size_t)b * DIM * Mpad;
-    const float tx = tb[j], ty = tb[(size_t)Mpad + j];
-    float n = __builtin_fmaf(ty, ty, tx * tx);
-    if constexpr (DIM == 3) {
-        const float tz = tb[(size_t)2 * Mpad + j];
-        n = __builtin_fmaf(tz, tz, n);
-    }
-    tnorm[(size_t)b * Mpad + j] = n;
-}
-
 template <int DIM, int P, int SUB>
 __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
-    const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ tnorm,
+    const float *__restrict__ src, const float *__restrict__ tgtp,
     const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx, int B,
     int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
     unsigned long long *__restrict__ packed)
@@ -265,7 +249,6 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
         const float *tb = tgtp + (size_t)b * DIM * Mpad;
-        const float *tnb = tnorm + (size_t)b * Mpad;
 
         float p[P][DIM], a[P][DIM], pn[P], brun[P], cur[P];
         int pidx[P], jj[P];
@@ -294,9 +277,17 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
             if (prev_idx != nullptr && i < N) {
                 const int j = prev_idx[(size_t)b * N + i];
                 if (j >= 0 && j < Mpad) {
-                    float e = __builtin_fmaf(tb[(size_t)Mpad + j], a[q][1], tnb[j]);
-                    if constexpr (DIM == 3) e = __builtin_fmaf(tb[(size_t)2 * Mpad + j], a[q][2], e);
-                    b0 = __builtin_fmaf(tb[j], a[q][0], e);
+                    const float jx = tb[j], jy = tb[(size_t)Mpad + j];
+                    float jn = __builtin_fmaf(jy, jy, jx * jx);
+                    float e = 0.f;
+                    if constexpr (DIM == 3) {
+                        const float jz = tb[(size_t)2 * Mpad + j];
+                        jn = __builtin_fmaf(jz, jz, jn);
+                        e = __builtin_fmaf(jz, a[q][2], __builtin_fmaf(jy, a[q][1], jn));
+                    } else {
+                        e = __builtin_fmaf(jy, a[q][1], jn);
+                    }
+                    b0 = __builtin_fmaf(jx, a[q][0], e);
                     b0 = (b0 == b0) ? b0 : INFINITY;
                 }
             }
@@ -315,7 +306,24 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
             for (int c = 0; c < DIM; ++c)
                 *reinterpret_cast<float4 *>(&lt[c][tid * 4]) =
                     *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
-            *reinterpret_cast<float4 *>(&lt[DIM][tid * 4]) = *reinterpret_cast<const float4 *>(tnb + (size_t)t * NN_TILE + tid * 4);
+            {   // |t|^2 of the four targets this thread staged (no norm plane in memory: it would add a third to the
+                // bytes a launch fetches)
+                const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][tid * 4]);
+                const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][tid * 4]);
+                float4 vn;
+                vn.x = __builtin_fmaf(vy.x, vy.x, vx.x * vx.x);
+                vn.y = __builtin_fmaf(vy.y, vy.y, vx.y * vx.y);
+                vn.z = __builtin_fmaf(vy.z, vy.z, vx.z * vx.z);
+                vn.w = __builtin_fmaf(vy.w, vy.w, vx.w * vx.w);
+                if constexpr (DIM == 3) {
+                    const float4 vz = *reinterpret_cast<const float4 *>(&lt[2][tid * 4]);
+                    vn.x = __builtin_fmaf(vz.x, vz.x, vn.x);
+                    vn.y = __builtin_fmaf(vz.y, vz.y, vn.y);
+                    vn.z = __builtin_fmaf(vz.z, vz.z, vn.z);
+                    vn.w = __builtin_fmaf(vz.w, vz.w, vn.w);
+                }
+                *reinterpret_cast<float4 *>(&lt[DIM][tid * 4]) = vn;
+            }
             __syncthreads();
             unsigned w[P];
 #pragma unroll
@@ -1257,7 +1265,7 @@ void launch_nn_t(const float *src, const float *tgtp, const float *Tk, const int
 }
 
 // `packed` (B,N) must hold NN_KEY_INIT on entry (memset 0xFF or re-armed by the accumulate kernel).
-int launch_nn(int dim, const float *src, const float *tgtp, const float *tnorm, const float *Tk, const int32_t *active,
+int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active,
               const int32_t *prev_idx, int B, int N, const NNPlan &pl, unsigned long long *packed, hipStream_t st)
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
@@ -1266,7 +1274,7 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *tnorm, 
         constexpr float U = 5.9604645e-8f;       // 2^-24
 #define MMK_PF_CASE(D, PP, SB, KAPPA)                                                                                     \
     if (dim == D && pl.P == PP && pl.chunk == SB)                                                                        \
-        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP, SB>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, tnorm, Tk, active, \
+        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP, SB>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, \
                            prev_idx, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
         MMK_PF_CASE(2, 2, 16, 48.0f); MMK_PF_CASE(2, 4, 16, 48.0f); MMK_PF_CASE(3, 2, 16, 64.0f); MMK_PF_CASE(3, 4, 16, 64.0f);
         MMK_PF_CASE(2, 2, 8, 48.0f); MMK_PF_CASE(2, 4, 8, 48.0f); MMK_PF_CASE(3, 2, 8, 64.0f); MMK_PF_CASE(3, 4, 8, 64.0f);
@@ -1293,16 +1301,6 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *tnorm, 
     return MMK_OK;
 }
 
-int pack_norm(int dim, const float *tgtp, int B, int Mpad, float *tnorm, hipStream_t st)
-{
-    if (dim == 2)
-        hipLaunchKernelGGL(pack_norm_kernel<2>, dim3(Mpad / 256, B), dim3(256), 0, st, tgtp, Mpad, tnorm);
-    else
-        hipLaunchKernelGGL(pack_norm_kernel<3>, dim3(Mpad / 256, B), dim3(256), 0, st, tgtp, Mpad, tnorm);
-    MMK_LAUNCH_CHECK();
-    return MMK_OK;
-}
-
 int check_params(const mmk_icp_params *p)
 {
     MMK_REQUIRE(p != nullptr, "mmk_icp: params is NULL");
@@ -1320,7 +1318,6 @@ int check_params(const mmk_icp_params *p)
 
 struct IcpWs {
     float *tgtp;
-    float *tnorm;                // (B,Mpad) |t|^2 of the planar target (pre-filtered scan)
     unsigned long long *packed;  // (B,N) NN keys
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
@@ -1338,7 +1335,6 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     mmk::Arena ar(ws, cap);
     IcpWs w;
     w.tgtp = ar.take<float>((size_t)p->B * p->dim * pl.Mpad);
-    w.tnorm = ar.take<float>((size_t)p->B * pl.Mpad);
     w.packed = ar.take<unsigned long long>((size_t)p->B * p->N);
     w.partials = ar.take<double>((size_t)p->B * nblk * 27);
     w.G0 = ar.take<double>((size_t)p->B * 16);
@@ -1398,7 +1394,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
         } else {
             // the correspondences of the previous iteration (still in the index buffer) start the filter's bound
             const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
-            int rc = launch_nn(DIM, src, w.tgtp, w.tnorm, Tk, act, prev, B, N, pl, w.packed, st);
+            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, prev, B, N, pl, w.packed, st);
             if (rc != MMK_OK) return rc;
         }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
@@ -1487,8 +1483,7 @@ extern "C" size_t mmk_nn_workspace_bytes(int32_t B, int32_t N, int32_t M, int32_
 {
     (void)dim;
     if (B < 1 || N < 1 || M < 1) return 0;
-    return mmk::align_up((size_t)B * N * sizeof(unsigned long long), 256) +
-           mmk::align_up((size_t)B * mmk_nn_padded_m(M) * sizeof(float), 256) + 512;
+    return mmk::align_up((size_t)B * N * sizeof(unsigned long long), 256) + 256;
 }
 
 extern "C" int mmk_nn_search(const float *source, const float *target_planar, const float *T, int32_t B, int32_t N,
@@ -1501,16 +1496,13 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     const NNPlan pl = nn_plan(B, N, M);
     mmk::Arena ar(workspace, workspace_bytes);
     unsigned long long *packed = ar.take<unsigned long long>((size_t)B * N);
-    float *tnorm = ar.take<float>((size_t)B * pl.Mpad);
     if (!ar.ok() || workspace == nullptr) {
         mmk::set_error("mmk_nn_search: workspace too small (%zu < %zu)", workspace_bytes, ar.off);
         return MMK_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     MMK_CHECK_HIP(hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
-    int rc = pack_norm(dim, target_planar, B, pl.Mpad, tnorm, st);
-    if (rc != MMK_OK) return rc;
-    rc = launch_nn(dim, source, target_planar, tnorm, T, nullptr, nullptr, B, N, pl, packed, st);
+    int rc = launch_nn(dim, source, target_planar, T, nullptr, nullptr, B, N, pl, packed, st);
     if (rc != MMK_OK) return rc;
     hipLaunchKernelGGL(nn_unpack_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, packed, B * N, idx, d2);
     MMK_LAUNCH_CHECK();
@@ -1572,10 +1564,6 @@ extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, con
     const int B = p->B;
     rc = mmk_pack_target(target, B, p->M, p->tgt_cols, p->dim, w.tgtp, stream);
     if (rc != MMK_OK) return rc;
-    if (p->nn_method == MMK_NN_BRUTE) {
-        rc = pack_norm(p->dim, w.tgtp, B, mmk_nn_padded_m(p->M), w.tnorm, st);
-        if (rc != MMK_OK) return rc;
-    }
     MMK_CHECK_HIP(hipMemcpyAsync(T_hist, T_init, sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, active_hist, B, 1);
     MMK_LAUNCH_CHECK();
