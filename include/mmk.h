@@ -310,6 +310,24 @@ int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, c
                              float scale, float leaky_slope, float *part, float *coef, void *gx, float *dW,
                              float *db, void *stream);
 
+/* nn.BatchNorm2d of the network's batch-norm variant (params["batch_norm"], icp_weight_policy.py:108-113) on NHWC
+ * bf16 (npix, C).  _forward_stats: batch statistics -> stat (C,2) = (mean, 1/sqrt(var + eps)) and affine (C,2) =
+ * (scale, shift); running_mean / running_var (both or neither) updated as torch does (momentum, unbiased variance);
+ * part: 512*C*2 floats of workspace.  _apply: y = a * scale + shift, then the block's inverted dropout (drop_p, seed;
+ * 0 = none); a kept zero is stored as -0.0, a dropped value as +0.0.  _backward: gd = dL/d(output), d = the stored
+ * post-dropout output when a dropout followed (else NULL; gy = gd * (d != +0 ? drop_scale : 0)), a = the BatchNorm
+ * input (= ReLU / LeakyReLU output); writes gz = dL/d(pre-activation of the convolution in front of the ReLU),
+ * dgamma / dbeta (accumulate != 0: adds -- decoder blocks run twice with shared modules); stat == NULL selects the
+ * evaluation-mode form gz = gy * scale * act'(a).  coef: 3*C floats of workspace. */
+int mmk_bn_forward_stats(const void *a, int64_t npix, int32_t C, const float *gamma, const float *beta, float eps,
+                         float momentum, float *running_mean, float *running_var, float *part, float *stat,
+                         float *affine, void *stream);
+int mmk_bn_apply(const void *a, int64_t npix, int32_t C, const float *affine, float drop_p, uint32_t seed, void *y,
+                 void *stream);
+int mmk_bn_backward(const void *gd, const void *d, float drop_scale, const void *a, int64_t npix, int32_t C,
+                    const float *stat, const float *affine, const float *gamma, float leaky_slope, int32_t accumulate,
+                    float *part, float *coef, float *dgamma, float *dbeta, void *gz, void *stream);
+
 /* ------------------------------------------------------------------ the mask U-Net as two calls
  * mmk_unet_forward replaces the network part of LearnICPWeightPolicy.forward
  * (mm_masking/icp_weight_policy.py:161-199: encoder, twice-applied decoder blocks, 1x1 + sigmoid, amax

@@ -119,6 +119,10 @@ def _declare(lib):
         "mmk_mask_normalize": (ctypes.c_int, [c_vp, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, f32, c_vp, c_vp,
                                                     c_vp, c_vp, c_vp, c_vp]),
+        "mmk_bn_forward_stats": (ctypes.c_int, [c_vp, ctypes.c_int64, i32, c_vp, c_vp, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_bn_apply": (ctypes.c_int, [c_vp, ctypes.c_int64, i32, c_vp, f32, ctypes.c_uint32, c_vp, c_vp]),
+        "mmk_bn_backward": (ctypes.c_int, [c_vp, c_vp, f32, c_vp, ctypes.c_int64, i32, c_vp, c_vp, c_vp, f32, i32, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp, c_vp]),
         "mmk_unet_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_unet_scratch_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_unet_forward": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp]),

@@ -2584,6 +2584,213 @@ __global__ __launch_bounds__(256) void channel_minmax_final_kernel(const float *
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// nn.BatchNorm2d of the network's batch-norm variant (params["batch_norm"], icp_weight_policy.py:108-113: it
+// follows the ReLU of each convolution), on NHWC bf16 tensors.  Training mode: batch statistics over (B,H,W) per
+// channel, fp32 partial sums per block in a fixed order + an fp64 final sum (deterministic), the running
+// statistics updated as torch does (momentum, unbiased variance).  The affine form y = a * scale + shift is applied
+// by a separate streaming pass that also draws the block's dropout (the Dropout module follows the second
+// BatchNorm).  A value that is kept but exactly zero is stored as -0.0 and a dropped one as +0.0, the convention of
+// the LeakyReLU variant: the backward kernels recover the dropout mask from the stored tensor alone.
+constexpr int BN_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16 *__restrict__ a, size_t npix, int C, float *__restrict__ part)
+{
+    __shared__ float red[256][17];
+    const int G = C >> 3, per = 256 / G;                  // granules per pixel, pixels per block pass
+    const int gc = threadIdx.x % G, pl = threadIdx.x / G;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (size_t p = (size_t)blockIdx.x * per + pl; p < npix; p += (size_t)gridDim.x * per) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4 *>(a + p * C + gc * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s[j] += v[j];
+            q[j] = __builtin_fmaf(v[j], v[j], q[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x][j] = s[j];
+        red[threadIdx.x][8 + j] = q[j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * 16; idx += blockDim.x) {
+        const int g2 = idx / 16, k = idx % 16;
+        float t = 0.f;
+        for (int r = 0; r < per; ++r) t += red[r * G + g2][k];
+        const int c = g2 * 8 + (k & 7);
+        part[((size_t)blockIdx.x * C + c) * 2 + (k >> 3)] = t;
+    }
+}
+
+// stat[c] = (mean, invstd); affine[c] = (scale, shift) = (gamma invstd, beta - mean gamma invstd)
+__global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, int C, double n, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float eps, float momentum, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, float *__restrict__ stat, float *__restrict__ affine)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((size_t)b * C + c) * 2];
+        q += (double)part[((size_t)b * C + c) * 2 + 1];
+    }
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    stat[2 * c] = (float)mean;
+    stat[2 * c + 1] = (float)invstd;
+    const double sc = (double)gamma[c] * invstd;
+    affine[2 * c] = (float)sc;
+    affine[2 * c + 1] = (float)((double)beta[c] - mean * sc);
+    if (running_mean != nullptr) {
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16 *__restrict__ a, size_t ngran, int C, const float *__restrict__ affine,
+                                                       float drop_p, unsigned seed, bf16 *__restrict__ y)
+{
+    const DropoutParams dp = dropout_params(drop_p);
+    const int G = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ngran; e += (size_t)gridDim.x * blockDim.x) {
+        const int gc = (int)(e % G);
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4 *>(a + e * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = __builtin_fmaf(v[j], affine[2 * (gc * 8 + j)], affine[2 * (gc * 8 + j) + 1]);
+            v[j] = (t == 0.f) ? -0.f : t;
+        }
+        if (drop_p > 0.f) {
+            float sc[4];
+            dropout_scale4(seed, (unsigned)(e * 8), dp, sc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = drop_leaky(v[j], sc[j]);
+            dropout_scale4(seed, (unsigned)(e * 8 + 4), dp, sc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 + j] = drop_leaky(v[4 + j], sc[j]);
+        }
+        *reinterpret_cast<u32x4 *>(y + e * 8) = pack8(v);
+    }
+}
+
+// gy = gd * (d != +0 ? drop_scale : 0) when the block's dropout followed this BatchNorm (d given), else gd
+__device__ __forceinline__ void bn_gy8(const bf16 *__restrict__ gd, const bf16 *__restrict__ d, size_t off, float drop_scale, float (&g)[8])
+{
+    unpack8(*reinterpret_cast<const u32x4 *>(gd + off), g);
+    if (d != nullptr) {
+        const u32x4 dv = *reinterpret_cast<const u32x4 *>(d + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[2 * j] = ((dv[j] & 0xffffu) != 0u) ? g[2 * j] * drop_scale : 0.f;
+            g[2 * j + 1] = ((dv[j] >> 16) != 0u) ? g[2 * j + 1] * drop_scale : 0.f;
+        }
+    }
+}
+
+// partial sums of gy and gy * xhat per channel (xhat = (a - mean) invstd)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16 *__restrict__ gd, const bf16 *__restrict__ d, float drop_scale,
+                                                            const bf16 *__restrict__ a, size_t npix, int C,
+                                                            const float *__restrict__ stat, float *__restrict__ part)
+{
+    __shared__ float red[256][17];
+    const int G = C >> 3, per = 256 / G;
+    const int gc = threadIdx.x % G, pl = threadIdx.x / G;
+    float mean[8], istd[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mean[j] = stat[2 * (gc * 8 + j)];
+        istd[j] = stat[2 * (gc * 8 + j) + 1];
+        s[j] = q[j] = 0.f;
+    }
+    for (size_t p = (size_t)blockIdx.x * per + pl; p < npix; p += (size_t)gridDim.x * per) {
+        float g[8], v[8];
+        bn_gy8(gd, d, p * C + gc * 8, drop_scale, g);
+        unpack8(*reinterpret_cast<const u32x4 *>(a + p * C + gc * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s[j] += g[j];
+            q[j] = __builtin_fmaf(g[j], (v[j] - mean[j]) * istd[j], q[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x][j] = s[j];
+        red[threadIdx.x][8 + j] = q[j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * 16; idx += blockDim.x) {
+        const int g2 = idx / 16, k = idx % 16;
+        float t = 0.f;
+        for (int r = 0; r < per; ++r) t += red[r * G + g2][k];
+        const int c = g2 * 8 + (k & 7);
+        part[((size_t)blockIdx.x * C + c) * 2 + (k >> 3)] = t;
+    }
+}
+
+// coef[c] = (gamma invstd, sum gy / n, sum gy xhat / n); dgamma / dbeta written or accumulated
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C, double n, const float *__restrict__ gamma,
+                                       const float *__restrict__ stat, int accumulate, float *__restrict__ coef,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((size_t)b * C + c) * 2];
+        q += (double)part[((size_t)b * C + c) * 2 + 1];
+    }
+    coef[3 * c] = gamma[c] * stat[2 * c + 1];
+    coef[3 * c + 1] = (float)(s / n);
+    coef[3 * c + 2] = (float)(q / n);
+    dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+}
+
+__global__ void bn_eval_coef_kernel(const float *__restrict__ affine, int C, float *__restrict__ coef)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) coef[3 * c] = affine[2 * c];
+}
+
+// gz = [k (gy - m1 - xhat m2)] * act'(a): the gradient w.r.t. the convolution's pre-activation.  Evaluation mode
+// (stat == nullptr): gz = gy * scale * act'(a), scale = coef[3c].
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16 *__restrict__ gd, const bf16 *__restrict__ d, float drop_scale,
+                                                           const bf16 *__restrict__ a, size_t ngran, int C,
+                                                           const float *__restrict__ stat, const float *__restrict__ coef, float slope,
+                                                           bf16 *__restrict__ gz)
+{
+    const int G = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ngran; e += (size_t)gridDim.x * blockDim.x) {
+        const int gc = (int)(e % G);
+        float g[8], v[8], o[8];
+        bn_gy8(gd, d, e * 8, drop_scale, g);
+        unpack8(*reinterpret_cast<const u32x4 *>(a + e * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = gc * 8 + j;
+            float ga;
+            if (stat != nullptr) {
+                const float xh = (v[j] - stat[2 * c]) * stat[2 * c + 1];
+                ga = coef[3 * c] * ((g[j] - coef[3 * c + 1]) - xh * coef[3 * c + 2]);
+            } else {
+                ga = g[j] * coef[3 * c];
+            }
+            // a is the ReLU / LeakyReLU output: for the leaky network a kept zero is -0.0 (negative side)
+            const float f = (slope > 0.f) ? ((v[j] > 0.f) ? 1.f : slope) : ((v[j] > 0.f) ? 1.f : 0.f);
+            o[j] = ga * f;
+        }
+        *reinterpret_cast<u32x4 *>(gz + e * 8) = pack8(o);
+    }
+}
+
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
 
 }  // namespace
@@ -2652,7 +2859,7 @@ extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
     a.o1 = {(bf16 *)d->y1, (const bf16 *)d->relu_src1, d->O1, d->accumulate1, d->scale1};
     a.o2 = {(bf16 *)d->y2, (const bf16 *)d->relu_src2, d->O2, d->accumulate2, d->scale2};
     a.B = d->B; a.H = d->H; a.W = d->W; a.CIN = cin; a.COUT = cout;
-    MMK_REQUIRE(d->leaky_slope >= 0.f && d->leaky_slope < 1.f, "mmk_conv3x3: leaky_slope must be in [0, 1)");
+    MMK_REQUIRE(d->leaky_slope >= 0.f && d->leaky_slope <= 1.f, "mmk_conv3x3: leaky_slope must be in [0, 1]");
     a.relu = d->relu; a.slope = d->leaky_slope; a.drop_p = d->drop_p; a.seed = d->seed;
     a.pool_y = (bf16 *)d->pool_y;
     return dispatch_conv(a, (hipStream_t)stream);
@@ -2732,6 +2939,67 @@ extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t
     a.dWt = nullptr; a.db = nullptr; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
     a.partials = partials; a.acc_partials = accumulate;
     return dispatch_wgrad(a, (hipStream_t)stream);
+}
+
+extern "C" int mmk_bn_forward_stats(const void *a, int64_t npix, int32_t C, const float *gamma, const float *beta, float eps,
+                                    float momentum, float *running_mean, float *running_var, float *part, float *stat, float *affine,
+                                    void *stream)
+{
+    MMK_REQUIRE(a && gamma && beta && part && stat && affine, "mmk_bn_forward_stats: NULL pointer");
+    MMK_REQUIRE(npix >= 1 && chan_ok(C) && C <= 2048, "mmk_bn_forward_stats: bad shape (npix %lld, C %d)", (long long)npix, C);
+    MMK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mmk_bn_forward_stats: running_mean / running_var go together");
+    hipStream_t st = (hipStream_t)stream;
+    const int per = 256 / (C / 8);
+    const int nblk = (int)std::min<int64_t>(BN_BLOCKS, (npix + per - 1) / per);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, st, (const bf16 *)a, (size_t)npix, C, part);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, nblk, C, (double)npix, gamma, beta, eps, momentum,
+                       running_mean, running_var, stat, affine);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_bn_apply(const void *a, int64_t npix, int32_t C, const float *affine, float drop_p, uint32_t seed, void *y,
+                            void *stream)
+{
+    MMK_REQUIRE(a && affine && y, "mmk_bn_apply: NULL pointer");
+    MMK_REQUIRE(npix >= 1 && chan_ok(C), "mmk_bn_apply: bad shape");
+    MMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mmk_bn_apply: dropout probability out of range");
+    const size_t ngran = (size_t)npix * (C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)std::min<size_t>((ngran + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16 *)a, ngran, C, affine, drop_p, seed, (bf16 *)y);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_bn_backward(const void *gd, const void *d, float drop_scale, const void *a, int64_t npix, int32_t C,
+                               const float *stat, const float *affine, const float *gamma, float leaky_slope, int32_t accumulate,
+                               float *part, float *coef, float *dgamma, float *dbeta, void *gz, void *stream)
+{
+    MMK_REQUIRE(gd && a && coef && gz, "mmk_bn_backward: NULL pointer");
+    MMK_REQUIRE(npix >= 1 && chan_ok(C) && C <= 2048, "mmk_bn_backward: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ngran = (size_t)npix * (C / 8);
+    const unsigned gb = (unsigned)std::min<size_t>((ngran + 255) / 256, 8192);
+    if (stat != nullptr) {          // training mode: batch statistics
+        MMK_REQUIRE(gamma && part && dgamma && dbeta, "mmk_bn_backward: NULL pointer (training mode)");
+        const int per = 256 / (C / 8);
+        const int nblk = (int)std::min<int64_t>(BN_BLOCKS, (npix + per - 1) / per);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, (const bf16 *)gd, (const bf16 *)d, drop_scale,
+                           (const bf16 *)a, (size_t)npix, C, stat, part);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, nblk, C, (double)npix, gamma, stat,
+                           accumulate, coef, dgamma, dbeta);
+        MMK_LAUNCH_CHECK();
+    } else {
+        MMK_REQUIRE(affine != nullptr, "mmk_bn_backward: evaluation mode needs the affine (scale, shift) pairs");
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, affine, C, coef);
+        MMK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gb), dim3(256), 0, st, (const bf16 *)gd, (const bf16 *)d, drop_scale, (const bf16 *)a,
+                       ngran, C, stat, coef, leaky_slope, (bf16 *)gz);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
 }
 
 static unsigned nblk(size_t n, int t) { return (unsigned)((n + t - 1) / t); }

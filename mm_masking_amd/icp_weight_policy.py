@@ -4,7 +4,8 @@
 
   * the mask U-Net in hand-written NHWC bf16 MFMA kernels (unet_hip.py ->
     csrc/mmk_unet.hip): ReLU (the reference's default) and LeakyReLU(0.1)
-    (``params["leaky"]``) networks, Cartesian or polar input of any size >= 32 x 32.
+    (``params["leaky"]``) networks, with or without BatchNorm (``params["batch_norm"]``,
+    unet_hip_bn.py), Cartesian or polar input of any size >= 32 x 32.
     There is no vendor-library (MIOpen) or CPU fallback on a HIP device; the
     ``nn.Module`` tree is the parameter store (identical ``state_dict``) and, with the
     explicit ``unet_backend="torch"`` on a CPU device, the host-logic mirror the CPU
@@ -184,10 +185,6 @@ class LearnICPWeightPolicy(nn.Module):
                 if not raw_in.is_cuda:
                     raise _lib.MmkError("the mask U-Net is a set of HIP kernels with no CPU path: params['device'] must be "
                                         "a HIP device (unet_backend='torch' is the CPU host-logic mirror used by tests)")
-                if self.batch_norm:
-                    raise NotImplementedError("params['batch_norm']=True is not implemented by the hand-written U-Net "
-                                              "(the reference's default is False, train_icp_weights.py:381); there is "
-                                              "no vendor-library fallback")
                 # any image of at least 32 x 32 (five floor-rounding poolings leave >= 1 pixel): the Cartesian
                 # 640 x 640 grid and the polar 400 x 3360 one (network_input_type "polar") alike
                 if raw_in.shape[1] > 4 or raw_in.shape[2] < 32 or raw_in.shape[3] < 32:
@@ -202,8 +199,13 @@ class LearnICPWeightPolicy(nn.Module):
                 else:
                     net_in, pre = self._normalize_channels(raw_in), None
                 # (the amax normalisation below rides inside the same autograd node)
-                weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre,
-                                                 slope=0.1 if self.leaky else 0.0)
+                if self.batch_norm:        # Conv, ReLU, BN, Conv, ReLU, BN: BatchNorm kernels between the convolutions
+                    from . import unet_hip_bn
+                    weight_mask = unet_hip_bn.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre,
+                                                        slope=0.1 if self.leaky else 0.0)
+                else:
+                    weight_mask = unet_hip.unet_mask(self, net_in, self.training, self._step, norm=self.norm_weights, pre=pre,
+                                                     slope=0.1 if self.leaky else 0.0)
                 normalised = self.norm_weights
             else:
                 if raw_in.is_cuda:

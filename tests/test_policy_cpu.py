@@ -77,3 +77,17 @@ def test_checkpoint_helpers(tmp_path):
     c = LearnICPWeightPolicy(p)
     assert trn.load_checkpoint(str(tmp_path / "epoch_0.pt"), c) == (0, None)
     assert all(torch.equal(va, vc) for va, vc in zip(a.state_dict().values(), c.state_dict().values()))
+
+
+def test_batch_norm_module_tree_matches_reference_keys(golden_dir):
+    """params["batch_norm"]: Conv, ReLU, BN, Conv, ReLU, BN (icp_weight_policy.py:104-125) -- the state_dict keys
+    (incl. running statistics) and the CPU mirror's mask equal the reference module's (unet_grads.npz, tag n)."""
+    g = np.load(os.path.join(golden_dir, "unet_grads.npz"), allow_pickle=False)
+    torch.manual_seed(1234)
+    model = LearnICPWeightPolicy(_params(batch_norm=True))
+    model.train()
+    assert list(model.state_dict().keys()) == [str(k) for k in g["sd_names_n"]]
+    xin = np.random.default_rng(99).uniform(0.01, 1, size=(2, 64, 64)).astype(np.float32)
+    scan = {"fft_data": torch.from_numpy(xin), "fft_cfar": torch.zeros(2, 64, 64), "raw_pc": torch.zeros(2, 4, 3)}
+    m = model(scan, {"pc": torch.zeros(2, 4, 6)}, None, mask_only=True)
+    np.testing.assert_allclose(m.detach().numpy(), g["mask_n"], atol=2e-6)
