@@ -6,7 +6,10 @@ tests).  The reference has no multi-GPU path; nothing is mirrored here.
 
 All parameter gradients are views into one contiguous buffer, so the collective
 needs no packing copies and a single launch: at 7 MB the ring is latency-bound
-(~0.1 ms against a step of tens of ms), so bucketing/overlap would buy nothing.
+(~0.1 ms against a step of ~12 ms), so bucketing/overlap would buy nothing.  The
+buffer is the one the U-Net backward itself writes (mmk_unet_backward's gradient
+block, adopted by autograd as the .grad tensors): the data-parallel step adds one
+all-reduce and one scale launch to the single-GPU step, nothing else.
 """
 import torch
 import torch.distributed as dist
@@ -43,13 +46,40 @@ class FlatGradSync:
                 dist.broadcast(p.data, src=src, group=self.pg)
 
     def zero_grad(self):
-        self._attach()
-        self.flat.zero_()
+        """Before the backward pass.  The gradients are dropped rather than zero-filled: the hand-written U-Net
+        backward returns all 46 gradients as views of ONE fresh contiguous buffer, which autograd adopts as the
+        ``.grad`` tensors when none exist -- and which ``__call__`` then all-reduces in place (no packing copies, no
+        46 accumulate launches).  Gradients produced any other way are packed into the bucket by ``__call__``."""
+        for p in self.params:
+            p.grad = None
+
+    def _adopt(self):
+        """The one buffer all gradients are views of, if they are (the native U-Net backward's layout)."""
+        g0 = self.params[0].grad
+        base = g0._base if g0 is not None else None
+        if base is None or base.dim() != 1 or base.dtype != torch.float32:
+            return None
+        lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * 4
+        for p in self.params:
+            g = p.grad
+            if g is None or g._base is not base or not g.is_contiguous() or not (lo <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= hi):
+                return None
+        return base
 
     def __call__(self):
         """Average the gradients over the ranks (call between backward and step)."""
-        self._attach()
         ws = self.world_size()
+        base = self._adopt()
+        if base is not None:
+            self.flat, self.views = base, [p.grad for p in self.params]
+        else:
+            # generic path: pack whatever .grad tensors exist into the bucket and make them views of it
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
         if ws > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
             self.flat.div_(ws)

@@ -538,7 +538,7 @@ class _UNetNative(torch.autograd.Function):
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + (n + 3) // 4 * 4)
-        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)   # (zeros: the alignment gaps are summed by a DDP all-reduce)
         grads = [flat[offs[i]:offs[i] + sizes[i]].view(P[i].shape) for i in range(len(P))]
         pp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in P])
         gp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in grads])
