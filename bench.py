@@ -374,7 +374,19 @@ def main():
             active_pairs = float(act.mean().item())
         alg_bytes = nn_algorithmic_bytes(1) * active_pairs
         achieved = alg_bytes / nn_avg_s / 1e9
-        evals = active_pairs * N_PAD * M_PAD       # distance evaluations per launch
+        # source rows a launch actually scans: blocks of 512 all-zero padding rows behind a pair's first zero row take that
+        # row's result instead (csrc/mmk_icp.hip: src_zero_scan_kernel) -- the evaluation count follows the rows scanned
+        scanned = float(N_PAD)
+        if model.ICP_alg.nn_search == "brute" and os.environ.get("MMK_NN_ZERO_DEDUP", "1") != "0" and \
+                os.environ.get("MMK_NN_PREFILTER", "1") != "0":
+            src_pts = trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD)["loc_data"]["filtered_pc"]
+            zero = (src_pts == 0).all(dim=-1)                                     # (B,N)
+            first_zero = torch.where(zero.any(dim=1), zero.float().argmax(dim=1), torch.full((B,), N_PAD, device=device))
+            blk_zero = zero.view(B, N_PAD // 512, 512).all(dim=2)
+            starts = torch.arange(0, N_PAD, 512, device=device).view(1, -1)
+            skipped = blk_zero & (first_zero.view(-1, 1) < starts)
+            scanned = float((N_PAD - 512 * skipped.sum(dim=1)).float().mean().item())
+        evals = active_pairs * scanned * M_PAD       # distance evaluations per launch
         # HBM bytes per launch from the PMC counters: measured in a separate rocprofv3 --pmc pass of this same
         # command (scripts/prof_nn.py -> profiles/r02_nn_traffic.json, committed); null when that file is absent
         traffic = None
@@ -400,7 +412,7 @@ def main():
                          "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else "nn_search_kernel<2,16,2>",
                          "nn_engine": model.ICP_alg.nn_search, "launches_timed": int(len(nn_ms)),
                          "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
-                         "active_pairs_per_launch": active_pairs,
+                         "active_pairs_per_launch": active_pairs, "source_rows_scanned_per_pair": scanned,
                          "note": "north_star names the HBM roofline; brute force does %.3g distance evaluations per "
                                  "launch over those bytes (~2.2 kFLOP/B), so the binding roofline is fp32 VALU" % evals,
                          "valu": {"pair_evals_per_s": evals / nn_avg_s,

@@ -224,24 +224,83 @@ __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
 // Work decomposition, XCD mapping and the 64-bit atomic-min merge of the target ranges are those of the scan above.
 constexpr int PF_CH = 32;            // targets per flag bit (32 chunks per LDS tile: one flag word per point and tile)
 
+// Identical source rows have identical nearest neighbours.  The reference pads every scan with all-zero rows up to the
+// largest cloud of the data set (icp_weight_dataset.py:377-381: about half of the 5 120 rows of a synthetic scan), and all
+// of them map to the same transformed point.  Once per icp() call this kernel finds, per pair, the first all-zero row
+// (zrep) and the source blocks that hold nothing else (allzero); a block that is all zero and lies behind zrep is not
+// scanned at all -- its rows take the key of row zrep, which an earlier block computed (icp_accumulate_kernel) --
+// exactly what the scan would have returned for them.
+__global__ __launch_bounds__(NN_THREADS) void src_zero_scan_kernel(const float *__restrict__ src, int N, int pts, int nsb,
+                                                                  int32_t *__restrict__ allzero, int32_t *__restrict__ zrep)
+{
+    const int sb = blockIdx.x, b = blockIdx.y;
+    int first = N;
+    int nonzero = 0;
+    for (int q = threadIdx.x; q < pts; q += blockDim.x) {
+        const int i = sb * pts + q;
+        if (i < N) {
+            const float *sp = src + ((size_t)b * N + i) * 3;
+            const bool z = sp[0] == 0.f && sp[1] == 0.f && sp[2] == 0.f;
+            nonzero |= z ? 0 : 1;
+            if (z && i < first) first = i;
+        }
+    }
+    const int any = __syncthreads_or(nonzero);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_down(first, off, 64));
+    if ((threadIdx.x & 63) == 0 && first < N) atomicMin(&zrep[b], first);
+    if (threadIdx.x == 0) allzero[(size_t)b * nsb + sb] = any ? 0 : 1;
+}
+
+// The source blocks that are scanned, as dense lists: one list per class b % 8 (the class picks the XCD whose L2 holds the
+// pair's target, as in the kernels' unit numbering), entries (b << 12 | sb) in ascending (b, sb); ucnt[c] = length of
+// list c, ucnt[8] = the longest.  With the skipped blocks gone from the numbering the persistent blocks of the NN kernel
+// all get the same amount of work (with `continue` on a skipped unit some blocks had two units and others none).
+__global__ void src_units_kernel(const int32_t *__restrict__ allzero, const int32_t *__restrict__ zrep, int B, int nsb, int pts,
+                                 int cap, int32_t *__restrict__ ulist, int32_t *__restrict__ ucnt)
+{
+    const int c = threadIdx.x;
+    int n = 0;
+    if (c < 8)
+        for (int b = c; b < B; b += 8)
+            for (int sb = 0; sb < nsb; ++sb)
+                if (!(allzero[(size_t)b * nsb + sb] != 0 && zrep[b] < sb * pts)) ulist[(size_t)c * cap + n++] = (b << 12) | sb;
+    if (c < 8) ucnt[c] = n;
+    int mx = n;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) mx = max(mx, __shfl_down(mx, off, 64));
+    if (c == 0) ucnt[8] = mx;
+}
+
 template <int DIM, int P, int SUB>
 __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
     const float *__restrict__ src, const float *__restrict__ tgtp,
-    const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx, int B,
+    const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx,
+    const int32_t *__restrict__ ulist, const int32_t *__restrict__ ucnt, int ucap, int B,
     int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
     unsigned long long *__restrict__ packed)
 {
     __shared__ __attribute__((aligned(16))) float lt[DIM + 1][NN_TILE];
     const int tid = threadIdx.x;
     const int ntiles = Mpad / NN_TILE;
+    // (zero-row deduplication on: the units are the listed source blocks x target ranges)
+    if (ulist != nullptr) total_units = ucnt[8] * ntu * 8;
 
     for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
         const int xcd = u & 7;
         int rest = u >> 3;
         const int tu = rest % ntu;
         rest /= ntu;
-        const int sb = rest % nsb;
-        const int b = (rest / nsb) * 8 + xcd;
+        int sb, b;
+        if (ulist != nullptr) {
+            if (rest >= ucnt[xcd]) continue;
+            const int code = ulist[(size_t)xcd * ucap + rest];
+            sb = code & 0xfff;
+            b = code >> 12;
+        } else {
+            sb = rest % nsb;
+            b = (rest / nsb) * 8 + xcd;
+        }
         if (b >= B) continue;
         if (active != nullptr && active[b] == 0) continue;
 
@@ -681,7 +740,9 @@ template <int DIM, int TYPE>
 __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
     const float *__restrict__ src, const float *__restrict__ tgt, int tgt_cols,
     const float *__restrict__ weight, const float *__restrict__ Tk, const int32_t *__restrict__ active,
-    unsigned long long *__restrict__ packed, int32_t *__restrict__ idx_out, int N, int M, int loss, float k,
+    const unsigned long long *__restrict__ packed, unsigned long long *__restrict__ packed_next,
+    const int32_t *__restrict__ allzero, const int32_t *__restrict__ zrep, int nn_pts, int nn_nsb,
+    int32_t *__restrict__ idx_out, int N, int M, int loss, float k,
     float k2, float trim2, double *__restrict__ partials)
 {
     constexpr int P = PointTerms<DIM, TYPE>::P;
@@ -698,9 +759,12 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
         float T[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) T[q] = Tk[(size_t)b * 16 + q];
-        // consume the NN key and re-arm it for the next iteration's atomic min
-        const unsigned long long key = packed[(size_t)b * N + i];
-        packed[(size_t)b * N + i] = NN_KEY_INIT;
+        // consume the NN key; arm the OTHER key buffer for the next iteration's atomic mins (two buffers: a row of a
+        // skipped all-zero block reads the key of the pair's first zero row, which another workgroup owns)
+        int isrc = i;
+        if (allzero != nullptr && allzero[(size_t)b * nn_nsb + i / nn_pts] != 0 && zrep[b] < (i / nn_pts) * nn_pts) isrc = zrep[b];
+        const unsigned long long key = packed[(size_t)b * N + isrc];
+        packed_next[(size_t)b * N + i] = NN_KEY_INIT;
         const int j = (int)(unsigned)(key & 0xffffffffull);
         idx_out[(size_t)b * N + i] = j;
         const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
@@ -1190,9 +1254,21 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
-    int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P;
+    int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P, ucap;
     bool prefilter;
 };
+
+
+// MMK_NN_ZERO_DEDUP=0: scan the all-zero padding rows of the source like any other row (A/B measurements)
+bool use_zero_dedup()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_NN_ZERO_DEDUP");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 // MMK_NN_PREFILTER=0 selects the plain scan (nn_search_kernel) instead of the pre-filtered one: same results,
 // A/B measurements (scripts/bench_nn.py)
@@ -1235,13 +1311,15 @@ NNPlan nn_plan(int B, int N, int M)
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
     pl.prefilter = use_nn_prefilter() && (pl.P == 2 || pl.P == 4);
-    // (pre-filtered scan: ranges of 2 tiles -- 3 200 units at the bench shape instead of 1 280 -- balance the CUs better,
-    // and a range without candidates below the starting bound costs no atomic: 224 -> 216 us per launch)
-    pl.tiles_per_unit = std::min((pl.prefilter && !tune.user) ? 2 : tune.tiles_per_unit, pl.ntiles);
+    // (pre-filtered scan: short ranges balance the CUs better, and a range without candidates below the starting bound
+    // costs no atomic.  Bench shape, 20 tiles: 5 tiles per unit 224 us, 2 tiles 216 us; with the zero-row blocks gone from
+    // the unit list 5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch)
+    pl.tiles_per_unit = std::min((pl.prefilter && !tune.user) ? 1 : tune.tiles_per_unit, pl.ntiles);
 
     pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
     pl.total_units = Bpad * pl.nsb * pl.ntu;
+    pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
     // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs)
     pl.grid = std::min(pl.total_units, 2048);
     return pl;
@@ -1266,7 +1344,8 @@ void launch_nn_t(const float *src, const float *tgtp, const float *Tk, const int
 
 // `packed` (B,N) must hold NN_KEY_INIT on entry (memset 0xFF or re-armed by the accumulate kernel).
 int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active,
-              const int32_t *prev_idx, int B, int N, const NNPlan &pl, unsigned long long *packed, hipStream_t st)
+              const int32_t *prev_idx, const int32_t *ulist, const int32_t *ucnt, int B, int N, const NNPlan &pl,
+              unsigned long long *packed, hipStream_t st)
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
@@ -1275,7 +1354,7 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
 #define MMK_PF_CASE(D, PP, SB, KAPPA)                                                                                     \
     if (dim == D && pl.P == PP && pl.chunk == SB)                                                                        \
         hipLaunchKernelGGL((nn_prefilter_kernel<D, PP, SB>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, \
-                           prev_idx, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
+                           prev_idx, ulist, ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
         MMK_PF_CASE(2, 2, 16, 48.0f); MMK_PF_CASE(2, 4, 16, 48.0f); MMK_PF_CASE(3, 2, 16, 64.0f); MMK_PF_CASE(3, 4, 16, 64.0f);
         MMK_PF_CASE(2, 2, 8, 48.0f); MMK_PF_CASE(2, 4, 8, 48.0f); MMK_PF_CASE(3, 2, 8, 64.0f); MMK_PF_CASE(3, 4, 8, 64.0f);
 #undef MMK_PF_CASE
@@ -1318,7 +1397,9 @@ int check_params(const mmk_icp_params *p)
 
 struct IcpWs {
     float *tgtp;
-    unsigned long long *packed;  // (B,N) NN keys
+    unsigned long long *packed;  // 2 x (B,N) NN keys: read by iteration k's accumulate, armed for iteration k+1
+    int32_t *allzero, *zrep;     // (B,nsb), (B): zero-row bookkeeping of the source (src_zero_scan_kernel)
+    int32_t *ulist, *ucnt;       // (8,ucap), (16): the source blocks the NN kernel scans (src_units_kernel)
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
     double *lam;        // backward (B,6)
@@ -1335,7 +1416,11 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     mmk::Arena ar(ws, cap);
     IcpWs w;
     w.tgtp = ar.take<float>((size_t)p->B * p->dim * pl.Mpad);
-    w.packed = ar.take<unsigned long long>((size_t)p->B * p->N);
+    w.packed = ar.take<unsigned long long>((size_t)2 * p->B * p->N);
+    w.allzero = ar.take<int32_t>((size_t)p->B * pl.nsb);
+    w.zrep = ar.take<int32_t>((size_t)p->B);
+    w.ulist = ar.take<int32_t>((size_t)8 * pl.ucap);
+    w.ucnt = ar.take<int32_t>(16);
     w.partials = ar.take<double>((size_t)p->B * nblk * 27);
     w.G0 = ar.take<double>((size_t)p->B * 16);
     w.G1 = ar.take<double>((size_t)p->B * 16);
@@ -1363,8 +1448,19 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
-    MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
+    MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)2 * B * N, st));
     const bool use_grid = p->nn_method == MMK_NN_GRID;
+    const int nn_pts = NN_THREADS * pl.P;
+    const bool dedup = !use_grid && pl.prefilter && use_zero_dedup() && pl.nsb <= 0xfff && B < (1 << 19);
+    if (dedup) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.zrep, B, N);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(src_zero_scan_kernel, dim3(pl.nsb, B), dim3(NN_THREADS), 0, st, src, N, nn_pts, pl.nsb, w.allzero, w.zrep);
+        MMK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(src_units_kernel, dim3(1), dim3(64), 0, st, w.allzero, w.zrep, B, pl.nsb, nn_pts, pl.ucap, w.ulist, w.ucnt);
+        MMK_LAUNCH_CHECK();
+    }
+    const int32_t *az = dedup ? w.allzero : nullptr, *zr = dedup ? w.zrep : nullptr;
     if (use_grid) {   // the target is fixed over the iterations: bin it once
         MMK_CHECK_HIP(hipMemsetAsync(w.g_counts, 0, sizeof(int32_t) * (size_t)B * GRID_NC * 2, st));
         hipLaunchKernelGGL(grid_count_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, tgt, M, p->tgt_cols, w.g_counts);
@@ -1379,13 +1475,14 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
         const float *Tk = T_hist + (size_t)it * B * 16;
         const int32_t *act = active_hist + (size_t)it * B;
         int32_t *idx = idx_hist + (p->save_state ? (size_t)it * B * N : 0);
+        unsigned long long *keys = w.packed + (size_t)(it & 1) * B * N, *keys_next = w.packed + (size_t)((it + 1) & 1) * B * N;
         if (use_grid) {
             const bool rec = g_prof.on && g_prof.n < g_prof.cap;
             if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
             // the correspondences of the previous iteration (still in the index buffer) bound the search
             const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
             hipLaunchKernelGGL(grid_nn_kernel<DIM>, dim3((N + 255) / 256, B), dim3(256), 0, st, src, Tk, act, w.g_starts,
-                               w.g_sorted, N, M, tgt, p->tgt_cols, prev, w.packed);
+                               w.g_sorted, N, M, tgt, p->tgt_cols, prev, keys);
             MMK_LAUNCH_CHECK();
             if (rec) {
                 MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
@@ -1394,11 +1491,12 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
         } else {
             // the correspondences of the previous iteration (still in the index buffer) start the filter's bound
             const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
-            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, prev, B, N, pl, w.packed, st);
+            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, prev, dedup ? w.ulist : nullptr, w.ucnt, B, N, pl, keys, st);
             if (rc != MMK_OK) return rc;
         }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
-                           p->tgt_cols, weight, Tk, act, w.packed, idx, N, M, p->loss, k, k2, trim2, w.partials);
+                           p->tgt_cols, weight, Tk, act, keys, keys_next, az, zr, nn_pts, pl.nsb, idx, N, M, p->loss, k, k2, trim2,
+                           w.partials);
         MMK_LAUNCH_CHECK();
         hipLaunchKernelGGL(icp_solve_kernel<DIM>, dim3(B), dim3(64), 0, st, w.partials, nblk, Tk,
                            T_hist + (size_t)(it + 1) * B * 16, delta_hist + (size_t)it * B * 6,
@@ -1502,7 +1600,7 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     }
     hipStream_t st = (hipStream_t)stream;
     MMK_CHECK_HIP(hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
-    int rc = launch_nn(dim, source, target_planar, T, nullptr, nullptr, B, N, pl, packed, st);
+    int rc = launch_nn(dim, source, target_planar, T, nullptr, nullptr, nullptr, nullptr, B, N, pl, packed, st);
     if (rc != MMK_OK) return rc;
     hipLaunchKernelGGL(nn_unpack_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, packed, B * N, idx, d2);
     MMK_LAUNCH_CHECK();
