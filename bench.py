@@ -409,7 +409,8 @@ def main():
                        "final_loss": float(loss)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else "nn_search_kernel<2,16,2>",
+                         "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else
+                         ("nn_search_kernel<2, 16, 2>" if os.environ.get("MMK_NN_PREFILTER", "1") == "0" else "nn_prefilter_kernel<2, 2, 16>"),
                          "nn_engine": model.ICP_alg.nn_search, "launches_timed": int(len(nn_ms)),
                          "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
                          "active_pairs_per_launch": active_pairs, "source_rows_scanned_per_pair": scanned,
@@ -418,7 +419,10 @@ def main():
                          "valu": {"pair_evals_per_s": evals / nn_avg_s,
                                   "achieved_tflops": evals * 6 / nn_avg_s / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": evals * 6 / nn_avg_s / 1e12 / VALU_PEAK_TFLOPS,
-                                  "flop_per_eval": 6}},
+                                  "flop_per_eval": 6,
+                                  "note": "6 = the normative distance (2 sub, mul, fma, compare); the pre-filtered scan issues 3 "
+                                          "vector instructions per evaluation (2 fma + min), i.e. frac is also its share of the "
+                                          "fp32 issue rate (157.3 TFLOP/s = 78.6e12 lane-instructions/s)"}},
         }
         if world == 1:
             result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)

@@ -14,3 +14,22 @@ with open(sys.argv[2], "w", newline="") as f:
     for name, calls, total, avg in rows:
         w.writerow([name, calls, int(total), "%.1f" % avg, "%.3f" % (100.0 * total / tot)])
 print("kernels: %d, total %.3f ms" % (len(rows), tot / 1e6))
+
+# ---- GPU idle time between kernels over the last 20 steps (a step = 10 NN launches): span of the region, time with at
+# least one kernel running, and the idle remainder per kernel boundary
+try:
+    ks = db.execute("select name, start, end from kernels order by start").fetchall()
+    nn = [i for i, k in enumerate(ks) if "nn_prefilter" in k[0] or "nn_search" in k[0] or "grid_nn" in k[0]]
+    if len(nn) > 210:
+        i0, i1 = nn[-201], nn[-1]
+        reg = ks[i0:i1]
+        span = reg[-1][2] - reg[0][1]
+        busy, cur_end = 0, reg[0][1]
+        for _, s, e in reg:
+            if e > cur_end:
+                busy += e - max(s, cur_end)
+                cur_end = e
+        print("last 20 steps: %d kernels, span %.3f ms/step, busy %.3f ms/step, idle %.3f ms/step = %.2f us per kernel boundary; sum of durations %.3f ms/step"
+              % (len(reg), span / 20e6, busy / 20e6, (span - busy) / 20e6, (span - busy) / 1e3 / len(reg), sum(e - s for _, s, e in reg) / 20e6))
+except Exception as ex:                                                      # (older rocpd schemas)
+    print("gap analysis skipped:", ex)
