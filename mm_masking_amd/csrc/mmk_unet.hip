@@ -795,7 +795,7 @@ struct DeepCfg {
     static constexpr int NW = NS * MTB * 64;
     static constexpr int RIN = (NIN + DEEP_THREADS - 1) / DEEP_THREADS;
     static constexpr int RW = (NW + DEEP_THREADS - 1) / DEEP_THREADS;
-    static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16);
+    static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16) + BM * sizeof(float);   // (+ the bias)
 };
 
 template <int BM, int NT, bool LK = false>
@@ -822,7 +822,10 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     if (tile >= t_end) return;
 
     u32x4 rin[RIN], rw[RW];
-    int g_dy[RIN], g_dx[RIN], g_c[RIN];
+    // Per lane and granule, once: position inside the halo tile.  Inside the loop an address is "uniform halo origin of the
+    // tile (scalar unit) + 32-bit lane offset": a multiply-add, two compares and a pointer select per 16-byte load instead of a
+    // 64-bit index computation (6 quarter-rate multiplies among ~45 instructions per load).
+    int g_dy[RIN], g_dx[RIN], g_c[RIN], g_pix[RIN];
 #pragma unroll
     for (int i = 0; i < RIN; ++i) {
         int g = tid + i * DEEP_THREADS;
@@ -831,6 +834,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         g_dy[i] = pix / WT - 1;
         g_dx[i] = pix % WT - 1;
         g_c[i] = (g % GPP) * 8;
+        g_pix[i] = (pix / WT) * a.W + pix % WT;       // pixel offset from the halo origin (row -1, column -1 of the tile)
     }
     auto load_in = [&](int t, int chunk) {
         const int b = t / tpi, tr = t - b * tpi;
@@ -841,12 +845,13 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         const bool in1 = c0 < a.C1;
         const bf16 *xb = in1 ? a.x1 : a.x2;
         const int xc = in1 ? a.C1 : a.C2, cb = in1 ? c0 : c0 - a.C1;
+        const long org = ((long)b * a.H + ty0 - 1) * a.W + tx0 - 1;            // halo origin pixel (may lie outside the image)
+        const bf16 *base = xb + org * xc + cb;
 #pragma unroll
         for (int i = 0; i < RIN; ++i) {
-            const int yy = ty0 + g_dy[i], xx = tx0 + g_dx[i];
-            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(xb + p * xc + cb + g_c[i]) : &g_zero16;
+            const bool ok = (unsigned)(ty0 + g_dy[i]) < (unsigned)a.H && (unsigned)(tx0 + g_dx[i]) < (unsigned)a.W;
+            const unsigned off = (unsigned)(g_pix[i] * xc + g_c[i]);
+            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(base + off) : &g_zero16;
             rin[i] = *sp;
         }
     };
@@ -859,18 +864,20 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         }
     };
 
-    // the accumulators start from the bias (re-read per tile: keeping it in registers across the MFMA
-    // loop would not fit)
+    // The bias of the block's channels sits in LDS behind the weights and is added in the epilogue (the accumulators
+    // start from zero).  A global load of it per tile, issued behind the epilogue's stores, made the first MFMA of the next
+    // tile wait for those stores to drain: loads and stores share one counter and complete out of order with each other.
+    float *bias_lds = reinterpret_cast<float *>(w_lds + (size_t)NW * 8);
+    if (tid < BM) {
+        const int c = group * BM + tid;
+        bias_lds[tid] = (a.bias && c < a.COUT) ? a.bias[c] : 0.f;
+    }
     f32x4 acc[MT][NT];
     auto reset_acc = [&]() {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int c0 = group * BM + (wm * MT + m) * 16 + (lane >> 4) * 4;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && c0 < a.COUT) bv = *reinterpret_cast<const f32x4 *>(a.bias + c0);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = bv;
-        }
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     reset_acc();
 
@@ -920,6 +927,13 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
             }
         }
+        // The prefetched stage has had the whole MFMA loop to arrive: take delivery of it HERE, in front of the epilogue's
+        // stores.  Left to the top of the next stage, the wait for these loads is a wait for "everything", i.e. for the
+        // stores to drain, with the matrix cores idle (loads and stores share vmcnt and complete out of order).
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) asm volatile("" : "+v"(rin[i]));
+#pragma unroll
+        for (int i = 0; i < RW; ++i) asm volatile("" : "+v"(rw[i]));
         if (chunk == nchunk - 1) {
             const int b = tile / tpi, tr = tile - b * tpi;
             const int tyi = tr / tiles_x;
@@ -995,9 +1009,10 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             float v[4];
+                            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + (wm * 4 + m) * 16 + g4 * 4);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[m][n][r];
+                                v[r] = acc[m][n][r] + bv[r];
                                 if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
@@ -1049,6 +1064,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                     const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
                     const float o_scale = firstp ? a.o1.scale : a.o2.scale;
                     const int cl = firstp ? c0 : c0 - a.o1.C;
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + (wm * MT + m) * 16 + (lv >> 4) * 4);
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int xx = tx0 + n * 16 + (lv & 15);
@@ -1057,7 +1073,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[m][n][r];
+                                v[r] = acc[m][n][r] + bv[r];
                                 if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
                             }
                             if (a.drop_p > 0.f) {
