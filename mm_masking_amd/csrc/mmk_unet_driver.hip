@@ -43,6 +43,7 @@ struct Plan {
     size_t packs_t[NCONV];
     size_t part[NCONV];                         // partial slices / atomic accumulators of layer k
     int slices[NCONV];
+    size_t zero_off = 0, zero_bytes = 0;     // scratch range of the atomically accumulated weight-gradient buffers
     size_t dB[NCONV];                           // bias sums of the atomic form
     size_t fin_ws;
     size_t scratch_bytes;
@@ -141,11 +142,20 @@ bool make_plan(Plan &p, int B, int H, int W, int cin, bool with_scratch)
             c1 = p.cinn[k];       // (the second application of a decoder block's first conv splits its input cs + cs:
                                   //  the slice count does not depend on the split for these shapes, checked at run time)
         }
-        const int ns = mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], c1, B, h, w);
-        p.slices[k] = ns;
-        const size_t per = (size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k];
-        p.part[k] = s.take((ns > 0 ? (size_t)ns : 1) * per * 4);
-        p.dB[k] = s.take((size_t)p.cout[k] * 4);
+        p.slices[k] = mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], c1, B, h, w);
+    }
+    // layers without a partial-sum kernel add into their (tap, cout, cin) buffer and bias sums with atomics: those buffers lie
+    // next to each other, so that one fill zeroes them all
+    p.zero_off = s.take(0);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k = 1; k <= 21; ++k) {
+            if ((p.slices[k] == 0) != (pass == 0)) continue;
+            const int ns = p.slices[k];
+            const size_t per = (size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k];
+            p.part[k] = s.take((ns > 0 ? (size_t)ns : 1) * per * 4);
+            p.dB[k] = s.take((size_t)p.cout[k] * 4);
+        }
+        if (pass == 0) p.zero_bytes = s.take(0) - p.zero_off;
     }
     p.fin_ws = s.take((size_t)B * 130 * 4);
     p.scratch_bytes = mmk::align_up(s.off, 256);
@@ -389,11 +399,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     MMK_CHECK_HIP(hipMemsetAsync(grads[1], 0, sizeof(float) * 8, st));
     MMK_CHECK_HIP(hipMemsetAsync(grads[44], 0, sizeof(float) * 8, st));
     MMK_CHECK_HIP(hipMemsetAsync(grads[45], 0, sizeof(float) * 1, st));
-    for (int k = 1; k <= 21; ++k)
-        if (p.slices[k] == 0) {
-            MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.part[k]), 0, sizeof(float) * 9 * p.cout[k] * p.cinn[k], st));
-            MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.dB[k]), 0, sizeof(float) * p.cout[k], st));
-        }
+    if (p.zero_bytes > 0) MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.zero_off), 0, p.zero_bytes, st));
     SideStream *ss = nullptr;
     if (use_side_stream()) MMK_TRY(side_stream(&ss));
     void *wstream = ss ? (void *)ss->st : stream;          // where the weight-gradient launches go

@@ -69,58 +69,78 @@ def prepare_batch(raw, params, max_loc_pts=5120, polar_res=0.0596):
     return {"loc_data": loc_data, "map_data": map_data, "transforms": T_data}
 
 
+_CONST_CACHE = {}
+
+
+def _const(kind, device, dtype):
+    """Read-only constants (a (1,) zero, the 4x4 identity) built once per device and dtype: the reference creates them
+    afresh in every call (train_icp_weights.py:183-188,195), which costs a fill launch each per training step."""
+    key = (kind, device, dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=dtype, device=device) if kind == "zero" else torch.eye(4, dtype=dtype, device=device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 def eval_training_loss(T_pred, mask, num_non0, batch_T_gt, batch_scan, batch_map, model, loss_weights=[],
                        icp_loss_only_iter=0, gt_eye=True, epoch=0):
-    """train_icp_weights.py:179-253."""
+    """train_icp_weights.py:179-253.  Same values and shapes as the reference's expression
+    ``w_rot * loss_rot + ... + w_num * loss_num_pts`` (a term that is switched off is a (1,) zero there, so the sum has
+    shape (1,) whenever one is); the switched-off terms are not multiplied and added on the GPU, though: they are a
+    shared constant zero (x + 0 = x bit for bit), which takes ~20 two-microsecond launches out of a training step."""
     mask_criterion = torch.nn.BCELoss()
     dev, dt = T_pred.device, T_pred.dtype
-    loss_rot = torch.zeros(1, device=dev)
-    loss_trans = torch.zeros(1, device=dev)
-    loss_fft = torch.zeros(1, device=dev)
-    loss_mask_pts = torch.zeros(1, dtype=dt, device=dev)
-    loss_cfar = torch.zeros(1, dtype=dt, device=dev)
-    loss_num_pts = torch.zeros(1, dtype=dt, device=dev)
+    zero = _const("zero", dev, dt)
+    terms = {"rot": None, "trans": None, "fft": None, "mask_pts": None, "cfar": None, "num_pts": None}
 
     if loss_weights["icp_rot"] > 0.0 or loss_weights["icp_trans"] > 0.0:
-        eye = torch.eye(4, dtype=dt, device=dev)
+        eye = _const("eye", dev, dt)
         if gt_eye:
             xi_wedge = T_pred - eye
         else:
             xi_wedge = torch.matmul(T_pred, torch.inverse(batch_T_gt)) - eye
         xi_r = xi_wedge[:, 0:2, 3]
         xi_theta = xi_wedge[:, 1, 0].unsqueeze(-1)
-        loss_rot = torch.norm(xi_theta, dim=1).mean()
-        loss_trans = torch.norm(xi_r, dim=1).mean()
+        terms["rot"] = torch.norm(xi_theta, dim=1).mean()
+        terms["trans"] = torch.norm(xi_r, dim=1).mean()
     if icp_loss_only_iter <= 0 or (icp_loss_only_iter > 0 and epoch < icp_loss_only_iter) or \
             (loss_weights["icp_rot"] <= 0 and loss_weights["icp_trans"] <= 0):
         if loss_weights["fft"] > 0.0:
             fft_data = batch_scan["fft_data"].to(mask.device)
             mean_azimuth = torch.mean(fft_data, dim=(1, 2), keepdim=True)
             fft_mask = torch.where(fft_data > 3.0 * mean_azimuth, torch.ones_like(fft_data), torch.zeros_like(fft_data))
-            loss_fft = mask_criterion(mask, fft_mask)
+            terms["fft"] = mask_criterion(mask, fft_mask)
         if loss_weights["cfar"] > 0.0:
-            loss_cfar = mask_criterion(mask, batch_scan["fft_cfar"].to(mask.device))
+            terms["cfar"] = mask_criterion(mask, batch_scan["fft_cfar"].to(mask.device))
         if loss_weights["mask_pts"] > 0.0:
             map_pts_mask = ru.extract_bev_from_pts(batch_map["pc"].to(mask.device))
-            loss_mask_pts = mask_criterion(mask, map_pts_mask)
+            terms["mask_pts"] = mask_criterion(mask, map_pts_mask)
         if loss_weights["num_pts"] > 0.0:
-            loss_num_pts = model.mean_all_pts - num_non0
+            terms["num_pts"] = model.mean_all_pts - num_non0
 
-    loss = loss_weights["icp_rot"] * loss_rot + loss_weights["icp_trans"] * loss_trans \
-        + loss_weights["fft"] * loss_fft + loss_weights["mask_pts"] * loss_mask_pts \
-        + loss_weights["cfar"] * loss_cfar + loss_weights["num_pts"] * loss_num_pts
-    loss_components = {"rot": (loss_weights["icp_rot"] * loss_rot).detach(),
-                       "trans": (loss_weights["icp_trans"] * loss_trans).detach(),
-                       "fft": (loss_weights["fft"] * loss_fft).detach(),
-                       "mask_pts": (loss_weights["mask_pts"] * loss_mask_pts).detach(),
-                       "cfar": (loss_weights["cfar"] * loss_cfar).detach(),
-                       "num_pts": (loss_weights["num_pts"] * loss_num_pts).detach()}
+    wkey = {"rot": "icp_rot", "trans": "icp_trans", "fft": "fft", "mask_pts": "mask_pts", "cfar": "cfar", "num_pts": "num_pts"}
+    loss = None
+    loss_components = {}
+    any_off = False
+    for name in ("rot", "trans", "fft", "mask_pts", "cfar", "num_pts"):     # the reference's order of summation
+        if terms[name] is None:
+            loss_components[name] = zero
+            any_off = True
+            continue
+        t = loss_weights[wkey[name]] * terms[name]
+        loss_components[name] = t.detach()
+        loss = t if loss is None else loss + t
+    if loss is None:
+        loss = zero.clone()
+    elif any_off and loss.dim() == 0:
+        loss = loss.reshape(1)
     return loss, loss_components
 
 
 def eval_validation_loss(T_pred, batch_T_gt, gt_eye=True):
     """train_icp_weights.py:255-273 -> [||(theta,x,y)||, |theta|, ||(x,y)||] batch means."""
-    eye = torch.eye(4, dtype=T_pred.dtype, device=T_pred.device)
+    eye = _const("eye", T_pred.device, T_pred.dtype)
     if gt_eye:
         xi_wedge = T_pred - eye
     else:
