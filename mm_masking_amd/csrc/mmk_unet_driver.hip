@@ -407,6 +407,26 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
         MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
     }
+    // parameter gradients of layers k0..k1: sum the slices / transpose, one launch on the weight-gradient stream, behind the
+    // weight-gradient launches enqueued so far
+    auto unpack = [&](int k0, int k1) -> int {
+        const float *src[21];
+        int32_t slices[21], co[21], ci[21];
+        float *dW[21], *db[21];
+        int n = 0;
+        for (int k = k0; k <= k1; ++k, ++n) {
+            src[n] = static_cast<const float *>(at(sc, p.part[k]));
+            slices[n] = p.slices[k]; co[n] = p.cout[k]; ci[n] = p.cinn[k];
+            dW[n] = grads[2 * k]; db[n] = grads[2 * k + 1];
+        }
+        const int rc = mmk_conv3x3_wgrad_unpack_batch(n, src, slices, co, ci, dW, db, wstream);
+        if (rc != MMK_OK) return rc;
+        for (int k = k0; k <= k1; ++k)
+            if (p.slices[k] == 0)
+                MMK_CHECK_HIP(hipMemcpyAsync(grads[2 * k + 1], at(sc, p.dB[k]), sizeof(float) * p.cout[k], hipMemcpyDeviceToDevice,
+                                             (hipStream_t)wstream));
+        return MMK_OK;
+    };
     bool part_used[NCONV] = {};
     auto wgrad = [&](int k, const void *x1, int C1, const void *x2, int C2, const void *g, int h, int w) -> int {
         if (ss) {   // g was produced by the launch just enqueued on the caller's stream
@@ -496,6 +516,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         if (i == 1) { c2.src1 = at(ws, p.t[0].off); c2.scale1 = s; }   // t[0] is an activation: factor, then accumulate
         MMK_TRY(conv(p, h, w, sl, c2, stream));
         g_t = tgt;
+        // every layer but the three at 640 x 640 has its weight gradients enqueued: reduce them now, under the rest of the chain
+        // (the reduction reads all partial slices -- most of them belong to the >= 64-channel layers -- and would otherwise
+        // be the tail of the backward pass)
+        if (i == 2) MMK_TRY(unpack(4, 21));
     }
     // ---- encoder block 0
     MMK_TRY(wgrad(1, at(ws, p.a_enc[0].off), 8, nullptr, 0, g_t, p.H, p.W));
@@ -506,23 +530,8 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_TRY(conv(p, p.H, p.W, sl, c, stream));
     }
     MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1], stream));
-    // ---- parameter gradients of the 21 3x3 layers: sum the slices / transpose, one launch
-    {
-        const float *src[21];
-        int32_t slices[21], co[21], ci[21];
-        float *dW[21], *db[21];
-        for (int k = 1; k <= 21; ++k) {
-            src[k - 1] = static_cast<const float *>(at(sc, p.part[k]));
-            slices[k - 1] = p.slices[k]; co[k - 1] = p.cout[k]; ci[k - 1] = p.cinn[k];
-            dW[k - 1] = grads[2 * k]; db[k - 1] = grads[2 * k + 1];
-        }
-        // (on the side stream, behind the last weight-gradient launch: it overlaps the tail of the main chain)
-        MMK_TRY(mmk_conv3x3_wgrad_unpack_batch(21, src, slices, co, ci, dW, db, wstream));
-        for (int k = 1; k <= 21; ++k)
-            if (p.slices[k] == 0)
-                MMK_CHECK_HIP(hipMemcpyAsync(grads[2 * k + 1], at(sc, p.dB[k]), sizeof(float) * p.cout[k], hipMemcpyDeviceToDevice,
-                                             (hipStream_t)wstream));
-    }
+    // ---- parameter gradients of the first three 3x3 layers (the rest was reduced while the 640 x 640 levels were still running)
+    MMK_TRY(unpack(1, 3));
     if (ss) {       // join: the caller's stream continues only after every gradient is written
         MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
         MMK_CHECK_HIP(hipStreamWaitEvent(st, ss->join, 0));
