@@ -33,3 +33,16 @@ try:
               % (len(reg), span / 20e6, busy / 20e6, (span - busy) / 20e6, (span - busy) / 1e3 / len(reg), sum(e - s for _, s, e in reg) / 20e6))
 except Exception as ex:                                                      # (older rocpd schemas)
     print("gap analysis skipped:", ex)
+
+# ---- optional: the last U-Net backward pass on a two-stream run, kernel by kernel (python rocpd_stats.py db out.csv timeline)
+if len(sys.argv) > 3 and sys.argv[3] == "timeline":
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    ks = db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")).fetchall()
+    last_fin = max(i for i, k in enumerate(ks) if "final_bwd" in k[0])
+    t0 = ks[last_fin][1]
+    for k in ks[last_fin:]:
+        nm = k[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
+        print("%9.1f %9.1f  q=%s  %s" % ((k[1] - t0) / 1e3, (k[2] - t0) / 1e3, k[3] if qcol else "?", nm))
+        if "multi_tensor_apply" in k[0]:
+            break
