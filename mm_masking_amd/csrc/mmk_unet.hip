@@ -1517,6 +1517,234 @@ int launch_wgrad(const WgradArgs &a, hipStream_t st)
 
 
 // ------------------------------------------------------------------------------------------
+// Backward pass of an 8 -> 8 "second convolution of a block" in ONE kernel.  Its data gradient (input: the output gradient g,
+// epilogue operand: the block's stored activation x as ReLU source) and its weight gradient (inputs: x and g) read the same
+// two tensors; as two kernels, on two streams, each of them streams both tensors from HBM and the pair takes as long side by
+// side as one after the other (both are bandwidth-bound at 640 x 640).  Here a block stages the halo tiles of x and of g once:
+// the weight-gradient contraction reads x with its halo and the interior of g (conv3x3_wgrad_kernel<8, 16, true>, same
+// fragment reads, same row order, same persistent tile walk and partial slices), the data gradient reads g with its halo and
+// takes the ReLU source from the interior of the x tile in LDS (conv3x3_ring_kernel<8, 16, ., true, false, true>: same
+// k-steps and the same 8-channel epilogue) -- 630 MB per launch at B = 32 instead of 1 050, results bit-identical to the
+// two-kernel path (tests/test_gpu_unet_kernels.py::test_bwd8_fused_bit_identical).
+struct Bwd8Args {
+    const bf16 *x, *g;       // (B,H,W,8) each
+    const bf16 *wpack_t;     // the data-gradient operator's packed weights (mmk_conv3x3_pack_weights, transposed = 1)
+    bf16 *dx;                // (B,H,W,8): ((x > 0) ? scale : 0) * conv_T(g)
+    float scale;
+    int B, H, W;
+    float *partials;         // [gridDim.x][9*8*8 + 8] partial sums of the weight / bias gradient
+    int acc_partials;
+};
+
+__global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const Bwd8Args a)
+{
+    constexpr int PK = 8, NTW = 2, NTT = 5, NS = 3, NT = 4;
+    constexpr int TILE = (HT * WT + 8) * PK;
+    __shared__ __attribute__((aligned(16))) bf16 x_tile[TILE];
+    __shared__ __attribute__((aligned(16))) bf16 g_tile[TILE];
+    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    // ---- weight-gradient side (conv3x3_wgrad_kernel<8, 16, true>)
+    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    unsigned b_ad[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nt = wv + 4 * n;
+        int tap = 2 * nt + (pp >> 1);
+        const int col = 4 * (pp & 1);
+        tap = tap > 8 ? 8 : tap;
+        const int ty = tap / 3, tx = tap % 3;
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PK + col) * 2);
+    }
+    // (the g tile carries its halo here: the interior starts one row and one column in)
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PK + 4 * pp) * 2);
+
+    // ---- data-gradient side (conv3x3_ring_kernel<8, 16, ., true, false, true>)
+    int d_lane[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int tap = 4 * ks + (lane >> 4);
+        tap = tap > 8 ? 8 : tap;
+        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PK;
+    }
+    const int n8 = lane >> 4;
+    const int lrow8 = 2 * wv + (n8 >> 1), lcol8 = (n8 & 1) * 16 + (lane & 15);
+    const int lpix8 = lrow8 * a.W + lcol8;
+    const int s_off8 = ((lrow8 + 1) * WT + lcol8 + 1) * PK;      // the lane's pixel in the x tile (ReLU source)
+    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
+
+    constexpr int NIN = HT * WT;                     // granules (8 channels = one granule per pixel) of a halo tile
+    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
+    u32x4 rx[RIN], rg[RIN];
+    auto load_tile = [&](int t) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NIN ? gi : NIN - 1;
+            const int dy = gi / WT - 1, dx = gi % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            const long p = (long)(pix0 + dy * a.W + dx) * 8;
+            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + p) : &g_zero16);
+            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + p) : &g_zero16);
+        }
+    };
+    auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NIN) {
+                *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * PK) = rx[i];
+                *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * PK) = rg[i];
+            }
+        }
+    };
+
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        {
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);
+        }
+        // ---- weight gradient: tile rows 0..7, the fragments of row r+1 in flight while row r is consumed
+        i32x2 fa[2][2], fb[2][2 * NTW];
+#define B8_ISSUE(R, BUF)                                                                     \
+    {                                                                                        \
+        fa[BUF][0] = tr_read_o<((R) * WT * PK) * 2>(g_ad);                                   \
+        fa[BUF][1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(g_ad);                         \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                        \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(b_ad[n]);          \
+        }                                                                                    \
+    }
+#define B8_CONSUME(BUF)                                                                      \
+    {                                                                                        \
+        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
+    }
+#define B8_STEP(R)                                                                           \
+    {                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((R) + 1 < TH) B8_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        B8_CONSUME((R) & 1);                                                                 \
+    }
+        B8_ISSUE(0, 0);
+        B8_STEP(0) B8_STEP(1) B8_STEP(2) B8_STEP(3) B8_STEP(4) B8_STEP(5) B8_STEP(6) B8_STEP(7)
+        static_assert(TH == 8, "B8_STEP expansion above covers 8 tile rows");
+#undef B8_STEP
+#undef B8_CONSUME
+#undef B8_ISSUE
+        // ---- data gradient of the tile
+        f32x4 dacc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const bf16 *bl = g_tile + d_lane[ks];
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PK);
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
+        }
+        const u32x4 e8_src = *reinterpret_cast<const u32x4 *>(x_tile + s_off8);
+        // the next tile's operands have had the MFMA work to arrive: take delivery in front of this tile's stores
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            asm volatile("" : "+v"(rx[i]));
+            asm volatile("" : "+v"(rg[i]));
+        }
+        {
+            const int b = t / tpi, tr = t - b * tpi;
+            const int tyi = tr / tiles_x;
+            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+            const int pix0 = (b * a.H + ty0) * a.W + tx0;
+            float v8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[0][r]), __float_as_uint(dacc[1][r]), false, false);
+                const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[2][r]), __float_as_uint(dacc[3][r]), false, false);
+                const auto lo = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+                v8[r] = __uint_as_float(lo[0]);
+                v8[4 + r] = __uint_as_float(hi[0]);
+            }
+            float sv[8];
+            unpack8(e8_src, sv);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                // (the two additions of zero are the ring kernel's bias and accumulate-target additions: they turn -0 into +0)
+                const float v = fmaxf(v8[r] + 0.f, -INFINITY);
+                const float masked = (sv[r] > 0.f) ? v * a.scale : 0.f;
+                v8[r] = masked + 0.f;
+            }
+            const bool ok8 = (ty0 + lrow8) < a.H && (tx0 + lcol8) < a.W;
+            u32x4 *dst8 = ok8 ? reinterpret_cast<u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : reinterpret_cast<u32x4 *>(g_sink16);
+            *dst8 = pack8(v8);
+        }
+    }
+
+    // ---- flush the block's partial slice (as conv3x3_wgrad_kernel<8, 16, true> with COUT = CIN = 8)
+    constexpr size_t pstride = (size_t)9 * 8 * 8 + 8;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = g4 * 4 + rr;
+        if (co >= 8) continue;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int nt = wv + 4 * n;
+            if (nt >= NTT) continue;
+            const int tap = 2 * nt + (i16 >> 3), ci = i16 & 7;
+            if (tap < 9) {
+                float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 8 + co) * 8 + ci;
+                *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+            }
+        }
+        if (wv == 0 && i16 == 0) {
+            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 8 * 8 + co;
+            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Weight gradient of the layers with >= 64 channels on both sides: 8 waves per block (two per
 // SIMD) on a 64 (co) x 64 (ci) x 9 (taps) slice.  Wave (wm, wc) owns 2 co-tiles x 1 ci-tile
 // x 9 taps.  The contraction walks the halo rows rho of a tile: the three x fragments of row
@@ -2932,6 +3160,22 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
         hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
         MMK_LAUNCH_CHECK();
     }
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv8_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
+                                   void *dx, float *partials, int32_t accumulate, void *stream)
+{
+    MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv8_bwd_fused: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv8_bwd_fused: bad shape");
+    MMK_REQUIRE((size_t)B * H * W * 8 < ((size_t)1 << 31), "mmk_conv8_bwd_fused: tensor too large for 32-bit offsets");
+    const int spatial = wgrad_slices(8, 8, 8, B, H, W);        // the partial slices of the two-kernel path: same layout, same sums
+    MMK_REQUIRE(spatial >= 1, "mmk_conv8_bwd_fused: occupancy query failed");
+    Bwd8Args a;
+    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
+    a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
+    hipLaunchKernelGGL(conv8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
+    MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
 

@@ -410,6 +410,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     // parameter gradients of layers k0..k1: sum the slices / transpose, one launch on the weight-gradient stream, behind the
     // weight-gradient launches enqueued so far
     auto unpack = [&](int k0, int k1) -> int {
+        if (ss) {   // (some slices were written on the caller's stream: the fused 8 -> 8 backward launches)
+            MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
+            MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
+        }
         const float *src[21];
         int32_t slices[21], co[21], ci[21];
         float *dW[21], *db[21];
@@ -428,6 +432,15 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         return MMK_OK;
     };
     bool part_used[NCONV] = {};
+    // 8 -> 8 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the caller's
+    // stream -- both read the block's activation and the output gradient (MMK_UNET_BWD8_FUSED=0: two launches)
+    static const bool fuse8_env = !(getenv("MMK_UNET_BWD8_FUSED") && getenv("MMK_UNET_BWD8_FUSED")[0] == '0');
+    auto bwd8 = [&](int k, const void *x, const void *g, void *dx, int h, int w) -> int {
+        const int rc = mmk_conv8_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, dx, static_cast<float *>(at(sc, p.part[k])),
+                                           part_used[k] ? 1 : 0, stream);
+        part_used[k] = true;
+        return rc;
+    };
     auto wgrad = [&](int k, const void *x1, int C1, const void *x2, int C2, const void *g, int h, int w) -> int {
         if (ss) {   // g was produced by the launch just enqueued on the caller's stream
             MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
@@ -465,11 +478,17 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         const int k0 = 12 + 2 * j, k1 = 13 + 2 * j;
         const void *skip = at(ws, p.t[4 - j].off);
         // second application
-        MMK_TRY(wgrad(k1, at(ws, p.a2[j].off), cs, nullptr, 0, gz, h, w));
-        ConvCall c;
-        c.x1 = gz; c.C1 = cs; c.wpack = at(sc, p.packs_t[k1]); c.y1 = at(sc, p.gz_a2[j].off); c.O1 = cs;
-        c.src1 = at(ws, p.a2[j].off); c.scale1 = 1.f;
-        MMK_TRY(conv(p, h, w, sl, c, stream));
+        const bool fuse8 = fuse8_env && cs == 8 && sl == 0.f && p.slices[k1] > 0 &&
+                           mmk_conv3x3_wgrad_slices(8, 8, 8, B, h, w) == p.slices[k1];
+        if (fuse8) {
+            MMK_TRY(bwd8(k1, at(ws, p.a2[j].off), gz, at(sc, p.gz_a2[j].off), h, w));
+        } else {
+            MMK_TRY(wgrad(k1, at(ws, p.a2[j].off), cs, nullptr, 0, gz, h, w));
+            ConvCall c;
+            c.x1 = gz; c.C1 = cs; c.wpack = at(sc, p.packs_t[k1]); c.y1 = at(sc, p.gz_a2[j].off); c.O1 = cs;
+            c.src1 = at(ws, p.a2[j].off); c.scale1 = 1.f;
+            MMK_TRY(conv(p, h, w, sl, c, stream));
+        }
         MMK_TRY(wgrad(k0, skip, cs, at(ws, p.d1[j].off), cs, at(sc, p.gz_a2[j].off), h, w));
         ConvCall c2;       // one pass, two outputs: the skip's gradient and the first application's output gradient
         c2.x1 = at(sc, p.gz_a2[j].off); c2.C1 = cs; c2.wpack = at(sc, p.packs_t[k0]);
@@ -478,11 +497,15 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         c2.y2 = at(sc, p.gz_d1[j].off); c2.O2 = cs; c2.src2 = at(ws, p.d1[j].off); c2.scale2 = s;
         MMK_TRY(conv(p, h, w, sl, c2, stream));
         // first application
-        MMK_TRY(wgrad(k1, at(ws, p.a1[j].off), cs, nullptr, 0, at(sc, p.gz_d1[j].off), h, w));
-        ConvCall c3;
-        c3.x1 = at(sc, p.gz_d1[j].off); c3.C1 = cs; c3.wpack = at(sc, p.packs_t[k1]); c3.y1 = at(sc, p.gz_a1[j].off); c3.O1 = cs;
-        c3.src1 = at(ws, p.a1[j].off); c3.scale1 = 1.f;
-        MMK_TRY(conv(p, h, w, sl, c3, stream));
+        if (fuse8) {
+            MMK_TRY(bwd8(k1, at(ws, p.a1[j].off), at(sc, p.gz_d1[j].off), at(sc, p.gz_a1[j].off), h, w));
+        } else {
+            MMK_TRY(wgrad(k1, at(ws, p.a1[j].off), cs, nullptr, 0, at(sc, p.gz_d1[j].off), h, w));
+            ConvCall c3;
+            c3.x1 = at(sc, p.gz_d1[j].off); c3.C1 = cs; c3.wpack = at(sc, p.packs_t[k1]); c3.y1 = at(sc, p.gz_a1[j].off); c3.O1 = cs;
+            c3.src1 = at(ws, p.a1[j].off); c3.scale1 = 1.f;
+            MMK_TRY(conv(p, h, w, sl, c3, stream));
+        }
         MMK_TRY(wgrad(k0, at(ws, p.u[j].off), 2 * cs, nullptr, 0, at(sc, p.gz_a1[j].off), h, w));
         ConvCall c4;
         c4.x1 = at(sc, p.gz_a1[j].off); c4.C1 = cs; c4.wpack = at(sc, p.packs_t[k0]); c4.y1 = at(sc, p.g_u[j].off); c4.O1 = 2 * cs;
@@ -522,8 +545,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         if (i == 2) MMK_TRY(unpack(4, 21));
     }
     // ---- encoder block 0
-    MMK_TRY(wgrad(1, at(ws, p.a_enc[0].off), 8, nullptr, 0, g_t, p.H, p.W));
-    {
+    if (fuse8_env && sl == 0.f && p.slices[1] > 0 && mmk_conv3x3_wgrad_slices(8, 8, 8, B, p.H, p.W) == p.slices[1]) {
+        MMK_TRY(bwd8(1, at(ws, p.a_enc[0].off), g_t, at(sc, p.gz_a[0].off), p.H, p.W));
+    } else {
+        MMK_TRY(wgrad(1, at(ws, p.a_enc[0].off), 8, nullptr, 0, g_t, p.H, p.W));
         ConvCall c;
         c.x1 = g_t; c.C1 = 8; c.wpack = at(sc, p.packs_t[1]); c.y1 = at(sc, p.gz_a[0].off); c.O1 = 8;
         c.src1 = at(ws, p.a_enc[0].off); c.scale1 = 1.f;

@@ -132,6 +132,16 @@ def conv3x3_wgrad_partial(x1, g, cout, partials, x2=None, accumulate=False):
     return partials
 
 
+def conv8_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
+    """Data gradient (ReLU source = x) and partial weight-gradient slices of an 8 -> 8 convolution in one launch:
+    bit-identical to conv3x3(g, wpack_t, 8, out=dx, relu_src=x, scale=scale) + conv3x3_wgrad_partial(x, g, 8, partials)."""
+    B, H, W, C = x.shape
+    assert C == 8 and g.shape == x.shape and dx.shape == x.shape
+    _lib.check(_lib.lib().mmk_conv8_bwd_fused(_p(x), _p(g), _p(wpack_t), float(scale), B, H, W, _p(dx), _p(partials),
+                                              1 if accumulate else 0, _lib.stream_ptr(x.device)))
+    return dx, partials
+
+
 def wgrad_unpack_batch(items):
     """One launch for a list of layers.  Each item is either a (9,cout,cin) tensor (atomic form) or a tuple
     (partials, cout, cin[, db_out]) of the partial-sum form; returns the (cout,cin,3,3) gradients (views of
