@@ -257,13 +257,13 @@ int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t 
 int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
                               int32_t B, int32_t H, int32_t W, float *partials, int32_t accumulate, void *stream);
 
-/* Backward pass of an 8 -> 8 convolution whose ReLU source IS its input activation (the second convolution of a U-Net block:
- * icp_weight_policy.py:115-121) in one launch: dx = ((x > 0) ? scale : 0) * conv_T(g) as mmk_conv3x3 gives it with
- * relu_src = x, and the partial slices of mmk_conv3x3_wgrad_partial(x, NULL, 8, 0, g, 8, ...) -- bit-identical to those two
- * calls, reading x and g once instead of twice.  wpack_t = mmk_conv3x3_pack_weights(W, 8, 8, transposed = 1);
- * partials holds mmk_conv3x3_wgrad_slices(8, 8, 8, B, H, W) slices of 9*8*8 + 8 floats. */
-int mmk_conv8_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
-                        void *dx, float *partials, int32_t accumulate, void *stream);
+/* Backward pass of a C -> C convolution (C = 8 or 16) whose ReLU source IS its input activation (the second convolution of
+ * a U-Net block: icp_weight_policy.py:115-121) in one launch: dx = ((x > 0) ? scale : 0) * conv_T(g) as mmk_conv3x3 gives it
+ * with relu_src = x, and the partial slices of mmk_conv3x3_wgrad_partial(x, NULL, C, 0, g, C, ...) -- bit-identical to those
+ * two calls, reading x and g once instead of twice.  wpack_t = mmk_conv3x3_pack_weights(W, C, C, transposed = 1);
+ * partials holds mmk_conv3x3_wgrad_slices(C, C, C, B, H, W) slices of 9*C*C + C floats. */
+int mmk_conv_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
+                       int32_t C, void *dx, float *partials, int32_t accumulate, void *stream);
 /* n layers in one launch (no accumulation): dW[i] (cout,cin,3,3) = src[i] (9,cout,cin) when slices is NULL or
  * slices[i] == 0; else the sum over the slices[i] partial slices of src[i], and db[i] (cout, optional) their
  * bias sums */

@@ -1744,6 +1744,202 @@ __global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const 
     }
 }
 
+// The same for a 16 -> 16 layer: conv3x3_wgrad_kernel<16, 16, false> + conv3x3_ring_kernel<16, 16, ., true, false, false>
+// (9 weight-gradient column tiles, 5 data-gradient k-steps of two taps, 4 channels of a pixel per lane in the epilogue).
+__global__ __launch_bounds__(CONV_THREADS) void conv16_bwd_fused_kernel(const Bwd8Args a)
+{
+    constexpr int C = 16, PK = 16, NTW = 3, NTT = 9, NS = 5, NT = 4;
+    constexpr int TILE = (HT * WT + 8) * PK;
+    __shared__ __attribute__((aligned(16))) bf16 x_tile[TILE];
+    __shared__ __attribute__((aligned(16))) bf16 g_tile[TILE];
+    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    unsigned b_ad[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        int tap = wv + 4 * n;
+        tap = tap > 8 ? 8 : tap;
+        const int ty = tap / 3, tx = tap % 3;
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PK + 4 * pp) * 2);
+    }
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PK + 4 * pp) * 2);
+
+    int d_lane[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int tap = 2 * ks + (lane >> 5);
+        const int ch = 8 * ((lane >> 4) & 1);
+        tap = tap > 8 ? 8 : tap;
+        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PK + ch;
+    }
+    int o_pix[NT], s_off[NT];                         // the lane's 4 channels of pixel (2 wv + n/2, 16 (n&1) + lane%16)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = 2 * wv + (n >> 1), c = (n & 1) * 16 + (lane & 15);
+        o_pix[n] = r * a.W + c;
+        s_off[n] = ((r + 1) * WT + c + 1) * PK + (lane >> 4) * 4;
+    }
+    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
+
+    constexpr int GPP = C / 8;
+    constexpr int NIN = HT * WT * GPP;
+    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
+    u32x4 rx[RIN], rg[RIN];
+    auto load_tile = [&](int t) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NIN ? gi : NIN - 1;
+            const int pix = gi / GPP, gc = gi % GPP;
+            const int dy = pix / WT - 1, dx = pix % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            const long p = (long)(pix0 + dy * a.W + dx) * C + gc * 8;
+            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + p) : &g_zero16);
+            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + p) : &g_zero16);
+        }
+    };
+    auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NIN) {
+                *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * 8) = rx[i];       // (granule gi = pixel gi / 2, half gi % 2)
+                *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * 8) = rg[i];
+            }
+        }
+    };
+
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        {
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);
+        }
+        i32x2 fa[2][2], fb[2][2 * NTW];
+#define B16_ISSUE(R, BUF)                                                                    \
+    {                                                                                        \
+        fa[BUF][0] = tr_read_o<((R) * WT * PK) * 2>(g_ad);                                   \
+        fa[BUF][1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(g_ad);                         \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                        \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(b_ad[n]);          \
+        }                                                                                    \
+    }
+#define B16_CONSUME(BUF)                                                                     \
+    {                                                                                        \
+        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
+    }
+#define B16_STEP(R)                                                                          \
+    {                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((R) + 1 < TH) B16_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);            \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        B16_CONSUME((R) & 1);                                                                \
+    }
+        B16_ISSUE(0, 0);
+        B16_STEP(0) B16_STEP(1) B16_STEP(2) B16_STEP(3) B16_STEP(4) B16_STEP(5) B16_STEP(6) B16_STEP(7)
+#undef B16_STEP
+#undef B16_CONSUME
+#undef B16_ISSUE
+        f32x4 dacc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const bf16 *bl = g_tile + d_lane[ks];
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PK);
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
+        }
+        bf16x4 e_src[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) e_src[n] = *reinterpret_cast<const bf16x4 *>(x_tile + s_off[n]);
+#pragma unroll
+        for (int i = 0; i < RIN; ++i) {
+            asm volatile("" : "+v"(rx[i]));
+            asm volatile("" : "+v"(rg[i]));
+        }
+        {
+            const int b = t / tpi, tr = t - b * tpi;
+            const int tyi = tr / tiles_x;
+            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+            const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bool okp = (ty0 + 2 * wv + (n >> 1)) < a.H && (tx0 + (n & 1) * 16 + (lane & 15)) < a.W;
+                bf16x4 outv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(dacc[n][r] + 0.f, -INFINITY);          // (the ring kernel's bias addition: -0 -> +0)
+                    const float masked = ((float)e_src[n][r] > 0.f) ? v * a.scale : 0.f;
+                    outv[r] = (bf16)(masked + 0.f);                               // (... and its accumulate-target addition)
+                }
+                bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(a.dx + ((long)(pix0 + o_pix[n]) * C + (lane >> 4) * 4))
+                                  : reinterpret_cast<bf16x4 *>(g_sink16);
+                *dst = outv;
+            }
+        }
+    }
+
+    constexpr size_t pstride = (size_t)9 * C * C + C;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = g4 * 4 + rr;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int tap = wv + 4 * n;
+            if (tap >= NTT) continue;
+            float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * C + co) * C + i16;
+            *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+        }
+        if (wv == 0 && i16 == 0) {
+            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * C * C + co;
+            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient of the layers with >= 64 channels on both sides: 8 waves per block (two per
 // SIMD) on a 64 (co) x 64 (ci) x 9 (taps) slice.  Wave (wm, wc) owns 2 co-tiles x 1 ci-tile
@@ -3163,18 +3359,19 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
     return MMK_OK;
 }
 
-extern "C" int mmk_conv8_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
-                                   void *dx, float *partials, int32_t accumulate, void *stream)
+extern "C" int mmk_conv_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
+                                  int32_t C, void *dx, float *partials, int32_t accumulate, void *stream)
 {
-    MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv8_bwd_fused: NULL pointer");
-    MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv8_bwd_fused: bad shape");
-    MMK_REQUIRE((size_t)B * H * W * 8 < ((size_t)1 << 31), "mmk_conv8_bwd_fused: tensor too large for 32-bit offsets");
-    const int spatial = wgrad_slices(8, 8, 8, B, H, W);        // the partial slices of the two-kernel path: same layout, same sums
-    MMK_REQUIRE(spatial >= 1, "mmk_conv8_bwd_fused: occupancy query failed");
+    MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv_bwd_fused: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2 && (C == 8 || C == 16), "mmk_conv_bwd_fused: bad shape (8 or 16 channels)");
+    MMK_REQUIRE((size_t)B * H * W * C < ((size_t)1 << 31), "mmk_conv_bwd_fused: tensor too large for 32-bit offsets");
+    const int spatial = wgrad_slices(C, C, C, B, H, W);        // the partial slices of the two-kernel path: same layout, same sums
+    MMK_REQUIRE(spatial >= 1, "mmk_conv_bwd_fused: occupancy query failed");
     Bwd8Args a;
     a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
-    hipLaunchKernelGGL(conv8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
+    if (C == 8) hipLaunchKernelGGL(conv8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -432,12 +432,15 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         return MMK_OK;
     };
     bool part_used[NCONV] = {};
-    // 8 -> 8 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the caller's
-    // stream -- both read the block's activation and the output gradient (MMK_UNET_BWD8_FUSED=0: two launches)
-    static const bool fuse8_env = !(getenv("MMK_UNET_BWD8_FUSED") && getenv("MMK_UNET_BWD8_FUSED")[0] == '0');
-    auto bwd8 = [&](int k, const void *x, const void *g, void *dx, int h, int w) -> int {
-        const int rc = mmk_conv8_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, dx, static_cast<float *>(at(sc, p.part[k])),
-                                           part_used[k] ? 1 : 0, stream);
+    // 8 -> 8 and 16 -> 16 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the
+    // caller's stream -- both read the block's activation and the output gradient (MMK_UNET_BWD_FUSED=0: two launches)
+    static const bool fuse_env = !(getenv("MMK_UNET_BWD_FUSED") && getenv("MMK_UNET_BWD_FUSED")[0] == '0');
+    auto can_fuse = [&](int k, int ch, int h, int w) {
+        return fuse_env && (ch == 8 || ch == 16) && sl == 0.f && p.slices[k] > 0 && mmk_conv3x3_wgrad_slices(ch, ch, ch, B, h, w) == p.slices[k];
+    };
+    auto bwd_fused = [&](int k, int ch, const void *x, const void *g, void *dx, int h, int w) -> int {
+        const int rc = mmk_conv_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, ch, dx, static_cast<float *>(at(sc, p.part[k])),
+                                          part_used[k] ? 1 : 0, stream);
         part_used[k] = true;
         return rc;
     };
@@ -478,10 +481,9 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         const int k0 = 12 + 2 * j, k1 = 13 + 2 * j;
         const void *skip = at(ws, p.t[4 - j].off);
         // second application
-        const bool fuse8 = fuse8_env && cs == 8 && sl == 0.f && p.slices[k1] > 0 &&
-                           mmk_conv3x3_wgrad_slices(8, 8, 8, B, h, w) == p.slices[k1];
+        const bool fuse8 = can_fuse(k1, cs, h, w);
         if (fuse8) {
-            MMK_TRY(bwd8(k1, at(ws, p.a2[j].off), gz, at(sc, p.gz_a2[j].off), h, w));
+            MMK_TRY(bwd_fused(k1, cs, at(ws, p.a2[j].off), gz, at(sc, p.gz_a2[j].off), h, w));
         } else {
             MMK_TRY(wgrad(k1, at(ws, p.a2[j].off), cs, nullptr, 0, gz, h, w));
             ConvCall c;
@@ -498,7 +500,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_TRY(conv(p, h, w, sl, c2, stream));
         // first application
         if (fuse8) {
-            MMK_TRY(bwd8(k1, at(ws, p.a1[j].off), at(sc, p.gz_d1[j].off), at(sc, p.gz_a1[j].off), h, w));
+            MMK_TRY(bwd_fused(k1, cs, at(ws, p.a1[j].off), at(sc, p.gz_d1[j].off), at(sc, p.gz_a1[j].off), h, w));
         } else {
             MMK_TRY(wgrad(k1, at(ws, p.a1[j].off), cs, nullptr, 0, at(sc, p.gz_d1[j].off), h, w));
             ConvCall c3;
@@ -525,11 +527,15 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     for (int i = 5; i >= 1; --i) {
         const int ch = ENC_CH[i], h = p.rh[i - 1], w = p.rw[i - 1];
         MMK_TRY(mmk_maxpool2_bwd(at(ws, p.d_enc[i].off), g_t, B, h, w, ch, s, sl, at(sc, p.gz_d[i].off), stream));
-        MMK_TRY(wgrad(2 * i + 1, at(ws, p.a_enc[i].off), ch, nullptr, 0, at(sc, p.gz_d[i].off), h, w));
-        ConvCall c;
-        c.x1 = at(sc, p.gz_d[i].off); c.C1 = ch; c.wpack = at(sc, p.packs_t[2 * i + 1]); c.y1 = at(sc, p.gz_a[i].off); c.O1 = ch;
-        c.src1 = at(ws, p.a_enc[i].off); c.scale1 = 1.f;
-        MMK_TRY(conv(p, h, w, sl, c, stream));
+        if (can_fuse(2 * i + 1, ch, h, w)) {
+            MMK_TRY(bwd_fused(2 * i + 1, ch, at(ws, p.a_enc[i].off), at(sc, p.gz_d[i].off), at(sc, p.gz_a[i].off), h, w));
+        } else {
+            MMK_TRY(wgrad(2 * i + 1, at(ws, p.a_enc[i].off), ch, nullptr, 0, at(sc, p.gz_d[i].off), h, w));
+            ConvCall c;
+            c.x1 = at(sc, p.gz_d[i].off); c.C1 = ch; c.wpack = at(sc, p.packs_t[2 * i + 1]); c.y1 = at(sc, p.gz_a[i].off); c.O1 = ch;
+            c.src1 = at(ws, p.a_enc[i].off); c.scale1 = 1.f;
+            MMK_TRY(conv(p, h, w, sl, c, stream));
+        }
         MMK_TRY(wgrad(2 * i, at(ws, p.t[i - 1].off), ENC_CH[i - 1], nullptr, 0, at(sc, p.gz_a[i].off), h, w));
         // data gradient accumulates into the skip gradient the decoder wrote for t[i-1]
         void *tgt = at(sc, p.gsk[5 - i].off);             // g_skip[i-1] was written by decoder block j = 4 - (i-1)
@@ -545,8 +551,8 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         if (i == 2) MMK_TRY(unpack(4, 21));
     }
     // ---- encoder block 0
-    if (fuse8_env && sl == 0.f && p.slices[1] > 0 && mmk_conv3x3_wgrad_slices(8, 8, 8, B, p.H, p.W) == p.slices[1]) {
-        MMK_TRY(bwd8(1, at(ws, p.a_enc[0].off), g_t, at(sc, p.gz_a[0].off), p.H, p.W));
+    if (can_fuse(1, 8, p.H, p.W)) {
+        MMK_TRY(bwd_fused(1, 8, at(ws, p.a_enc[0].off), g_t, at(sc, p.gz_a[0].off), p.H, p.W));
     } else {
         MMK_TRY(wgrad(1, at(ws, p.a_enc[0].off), 8, nullptr, 0, g_t, p.H, p.W));
         ConvCall c;

@@ -132,13 +132,13 @@ def conv3x3_wgrad_partial(x1, g, cout, partials, x2=None, accumulate=False):
     return partials
 
 
-def conv8_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
-    """Data gradient (ReLU source = x) and partial weight-gradient slices of an 8 -> 8 convolution in one launch:
-    bit-identical to conv3x3(g, wpack_t, 8, out=dx, relu_src=x, scale=scale) + conv3x3_wgrad_partial(x, g, 8, partials)."""
+def conv_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
+    """Data gradient (ReLU source = x) and partial weight-gradient slices of a C -> C convolution (C = 8, 16) in one launch:
+    bit-identical to conv3x3(g, wpack_t, C, out=dx, relu_src=x, scale=scale) + conv3x3_wgrad_partial(x, g, C, partials)."""
     B, H, W, C = x.shape
-    assert C == 8 and g.shape == x.shape and dx.shape == x.shape
-    _lib.check(_lib.lib().mmk_conv8_bwd_fused(_p(x), _p(g), _p(wpack_t), float(scale), B, H, W, _p(dx), _p(partials),
-                                              1 if accumulate else 0, _lib.stream_ptr(x.device)))
+    assert C in (8, 16) and g.shape == x.shape and dx.shape == x.shape
+    _lib.check(_lib.lib().mmk_conv_bwd_fused(_p(x), _p(g), _p(wpack_t), float(scale), B, H, W, C, _p(dx), _p(partials),
+                                             1 if accumulate else 0, _lib.stream_ptr(x.device)))
     return dx, partials
 
 

@@ -48,4 +48,4 @@ print("dgrad alone      %.1f us" % timeit(lambda: uh.conv3x3(g, wpt, 8, out=dx, 
 print("wgrad alone      %.1f us" % timeit(lambda: uh.conv3x3_wgrad_partial(x, g, 8, part)))
 print("both, one stream %.1f us" % timeit(two))
 print("both, 2 streams  %.1f us" % timeit(two_streams))
-print("fused            %.1f us" % timeit(lambda: uh.conv8_bwd_fused(x, g, wpt, 1.05, dx, part)))
+print("fused            %.1f us" % timeit(lambda: uh.conv_bwd_fused(x, g, wpt, 1.05, dx, part)))

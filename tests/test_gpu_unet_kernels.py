@@ -639,34 +639,35 @@ def test_conv3x3_eight_channel_epilogue_bit_identical():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C", [8, 16])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 37, 45), (1, 640, 640)])
-def test_bwd8_fused_bit_identical(B, H, W):
-    """mmk_conv8_bwd_fused == the data-gradient launch (ReLU source = the layer's input activation) + the partial
-    weight-gradient launch of an 8 -> 8 layer, bit for bit, including a second application that accumulates."""
+def test_bwd_fused_bit_identical(B, H, W, C):
+    """mmk_conv_bwd_fused == the data-gradient launch (ReLU source = the layer's input activation) + the partial
+    weight-gradient launch of a C -> C layer, bit for bit, including a second application that accumulates."""
     from mm_masking_amd import unet_hip as uh
     dev = torch.device("cuda:0")
-    g0 = torch.Generator(device="cpu").manual_seed(7)
-    x = (torch.randn(B, H, W, 8, generator=g0) * 0.7).clamp_min(0).to(dev).to(torch.bfloat16)       # a ReLU output: many zeros
-    g = (torch.randn(B, H, W, 8, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
-    w = (torch.randn(8, 8, 3, 3, generator=g0) / 8.0).to(dev)
+    g0 = torch.Generator(device="cpu").manual_seed(7 + C)
+    x = (torch.randn(B, H, W, C, generator=g0) * 0.7).clamp_min(0).to(dev).to(torch.bfloat16)       # a ReLU output: many zeros
+    g = (torch.randn(B, H, W, C, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
+    w = (torch.randn(C, C, 3, 3, generator=g0) / C).to(dev)
     wpt = uh.pack_weights(w, transposed=True)
-    ns = uh.wgrad_slices(8, 8, 8, B, H, W)
+    ns = uh.wgrad_slices(C, C, C, B, H, W)
     assert ns > 0
     ref_dx = torch.empty_like(x)
-    ref_part = uh.partial_buffer(ns, 8, 8, dev)
-    uh.conv3x3(g, wpt, 8, out=ref_dx, relu_src=x, scale=1.0 / 0.95)
-    uh.conv3x3_wgrad_partial(x, g, 8, ref_part)
+    ref_part = uh.partial_buffer(ns, C, C, dev)
+    uh.conv3x3(g, wpt, C, out=ref_dx, relu_src=x, scale=1.0 / 0.95)
+    uh.conv3x3_wgrad_partial(x, g, C, ref_part)
     dx = torch.full_like(x, 7.0)
     part = torch.full_like(ref_part, 3.0)
-    uh.conv8_bwd_fused(x, g, wpt, 1.0 / 0.95, dx, part)
+    uh.conv_bwd_fused(x, g, wpt, 1.0 / 0.95, dx, part)
     torch.cuda.synchronize()
     assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
     assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
     # second application of shared weights: accumulate into the same slices
     g2 = (g.float() * -0.5).to(torch.bfloat16)
-    uh.conv3x3_wgrad_partial(x, g2, 8, ref_part, accumulate=True)
-    uh.conv8_bwd_fused(x, g2, wpt, 1.0, dx, part, accumulate=True)
-    uh.conv3x3(g2, wpt, 8, out=ref_dx, relu_src=x, scale=1.0)
+    uh.conv3x3_wgrad_partial(x, g2, C, ref_part, accumulate=True)
+    uh.conv_bwd_fused(x, g2, wpt, 1.0, dx, part, accumulate=True)
+    uh.conv3x3(g2, wpt, C, out=ref_dx, relu_src=x, scale=1.0)
     torch.cuda.synchronize()
     assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
     assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
