@@ -264,6 +264,14 @@ int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t C1, int32_
  * partials holds mmk_conv3x3_wgrad_slices(C, C, C, B, H, W) slices of 9*C*C + C floats. */
 int mmk_conv_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
                        int32_t C, void *dx, float *partials, int32_t accumulate, void *stream);
+
+/* The same for the backward of an 8 -> 16 convolution whose data gradient (16 -> 8) takes the layer's input activation x as
+ * ReLU source and ADDS its result to what dx holds (first convolution of encoder block 1: the skip gradient is there
+ * already): dx += ((x > 0) ? scale : 0) * conv_T(g), as mmk_conv3x3 with relu_src = x, accumulate = 1, and the partial
+ * slices of mmk_conv3x3_wgrad_partial(x, NULL, 8, 0, g, 16, ...): mmk_conv3x3_wgrad_slices(16, 8, 8, B, H, W) slices of
+ * 9*16*8 + 16 floats.  x: (B,H,W,8), g: (B,H,W,16), wpack_t = mmk_conv3x3_pack_weights(W, 16, 8, transposed = 1). */
+int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
+                           void *dx, float *partials, int32_t accumulate, void *stream);
 /* n layers in one launch (no accumulation): dW[i] (cout,cin,3,3) = src[i] (9,cout,cin) when slices is NULL or
  * slices[i] == 0; else the sum over the slices[i] partial slices of src[i], and db[i] (cout, optional) their
  * bias sums */

@@ -1940,6 +1940,221 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16_bwd_fused_kernel(const Bw
     }
 }
 
+// ... and for the first convolution of encoder block 1 (8 -> 16 forward): its data gradient (16 -> 8) takes the stored
+// activation x = t[0] as ReLU source AND accumulates into the skip gradient the decoder left in dx, its weight gradient
+// reads the same x and the same g: conv3x3_wgrad_kernel<8, 16, false> + conv3x3_ring_kernel<16, 16, 2, true, false, true>.
+__global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const Bwd8Args a)
+{
+    constexpr int PX = 8, PG = 16, NTW = 2, NTT = 5, NS = 5, NT = 4;
+    __shared__ __attribute__((aligned(16))) bf16 x_tile[(HT * WT + 8) * PX];
+    __shared__ __attribute__((aligned(16))) bf16 g_tile[(HT * WT + 8) * PG];
+    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    // ---- weight-gradient side (x: 8 channels, g: 16 channels)
+    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    unsigned b_ad[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nt = wv + 4 * n;
+        int tap = 2 * nt + (pp >> 1);
+        const int col = 4 * (pp & 1);
+        tap = tap > 8 ? 8 : tap;
+        const int ty = tap / 3, tx = tap % 3;
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PX + col) * 2);
+    }
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PG + 4 * pp) * 2);
+
+    // ---- data-gradient side (input g: 16 channels, output: 8 channels)
+    int d_lane[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int tap = 2 * ks + (lane >> 5);
+        const int ch = 8 * ((lane >> 4) & 1);
+        tap = tap > 8 ? 8 : tap;
+        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PG + ch;
+    }
+    const int n8 = lane >> 4;
+    const int lrow8 = 2 * wv + (n8 >> 1), lcol8 = (n8 & 1) * 16 + (lane & 15);
+    const int lpix8 = lrow8 * a.W + lcol8;
+    const int s_off8 = ((lrow8 + 1) * WT + lcol8 + 1) * PX;
+    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
+
+    constexpr int NX = HT * WT, NG = HT * WT * 2;
+    constexpr int RX = (NX + CONV_THREADS - 1) / CONV_THREADS, RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
+    u32x4 rx[RX], rg[RG];
+    auto load_tile = [&](int t) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NX ? gi : NX - 1;
+            const int dy = gi / WT - 1, dx = gi % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + (long)(pix0 + dy * a.W + dx) * 8) : &g_zero16);
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NG ? gi : NG - 1;
+            const int pix = gi >> 1, gc = gi & 1;
+            const int dy = pix / WT - 1, dx = pix % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + (long)(pix0 + dy * a.W + dx) * 16 + gc * 8) : &g_zero16);
+        }
+    };
+    auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NX) *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * 8) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NG) *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * 8) = rg[i];
+        }
+    };
+
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
+        const bool ok8 = (ty0 + lrow8) < a.H && (tx0 + lcol8) < a.W;
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        // the accumulate target of this tile's epilogue, ahead of the next tile's operands in the load queue
+        const u32x4 e8_acc = *(ok8 ? reinterpret_cast<const u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : &g_zero16);
+        {
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);
+        }
+        i32x2 fa[2][2], fb[2][2 * NTW];
+#define BX_ISSUE(R, BUF)                                                                     \
+    {                                                                                        \
+        fa[BUF][0] = tr_read_o<((R) * WT * PG) * 2>(g_ad);                                   \
+        fa[BUF][1] = tr_read_o<((R) * WT * PG + 16 * PG) * 2>(g_ad);                         \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * PX) * 2>(b_ad[n]);                        \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PX + 16 * PX) * 2>(b_ad[n]);          \
+        }                                                                                    \
+    }
+#define BX_CONSUME(BUF)                                                                      \
+    {                                                                                        \
+        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
+    }
+#define BX_STEP(R)                                                                           \
+    {                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((R) + 1 < TH) BX_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        BX_CONSUME((R) & 1);                                                                 \
+    }
+        BX_ISSUE(0, 0);
+        BX_STEP(0) BX_STEP(1) BX_STEP(2) BX_STEP(3) BX_STEP(4) BX_STEP(5) BX_STEP(6) BX_STEP(7)
+#undef BX_STEP
+#undef BX_CONSUME
+#undef BX_ISSUE
+        f32x4 dacc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const bf16 *bl = g_tile + d_lane[ks];
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PG);
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
+        }
+        const u32x4 e8_src = *reinterpret_cast<const u32x4 *>(x_tile + s_off8);
+#pragma unroll
+        for (int i = 0; i < RX; ++i) asm volatile("" : "+v"(rx[i]));
+#pragma unroll
+        for (int i = 0; i < RG; ++i) asm volatile("" : "+v"(rg[i]));
+        {
+            float v8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[0][r]), __float_as_uint(dacc[1][r]), false, false);
+                const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[2][r]), __float_as_uint(dacc[3][r]), false, false);
+                const auto lo = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+                v8[r] = __uint_as_float(lo[0]);
+                v8[4 + r] = __uint_as_float(hi[0]);
+            }
+            float sv[8], av[8];
+            unpack8(e8_src, sv);
+            unpack8(e8_acc, av);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = fmaxf(v8[r] + 0.f, -INFINITY);                   // (the ring kernel's bias addition)
+                const float masked = (sv[r] > 0.f) ? v * a.scale : 0.f;
+                v8[r] = masked + av[r];
+            }
+            u32x4 *dst8 = ok8 ? reinterpret_cast<u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : reinterpret_cast<u32x4 *>(g_sink16);
+            *dst8 = pack8(v8);
+        }
+    }
+
+    // ---- flush (conv3x3_wgrad_kernel<8, 16, false> with COUT = 16, CIN = 8)
+    constexpr size_t pstride = (size_t)9 * 16 * 8 + 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = g4 * 4 + rr;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int nt = wv + 4 * n;
+            if (nt >= NTT) continue;
+            const int tap = 2 * nt + (i16 >> 3), ci = i16 & 7;
+            if (tap < 9) {
+                float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 16 + co) * 8 + ci;
+                *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+            }
+        }
+        if (wv == 0 && i16 == 0) {
+            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 16 * 8 + co;
+            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient of the layers with >= 64 channels on both sides: 8 waves per block (two per
 // SIMD) on a 64 (co) x 64 (ci) x 9 (taps) slice.  Wave (wm, wc) owns 2 co-tiles x 1 ci-tile
@@ -3372,6 +3587,22 @@ extern "C" int mmk_conv_bwd_fused(const void *x, const void *g, const void *wpac
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
     if (C == 8) hipLaunchKernelGGL(conv8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
+                                      void *dx, float *partials, int32_t accumulate, void *stream)
+{
+    MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv8x16_bwd_fused: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv8x16_bwd_fused: bad shape");
+    MMK_REQUIRE((size_t)B * H * W * 16 < ((size_t)1 << 31), "mmk_conv8x16_bwd_fused: tensor too large for 32-bit offsets");
+    const int spatial = wgrad_slices(16, 8, 8, B, H, W);
+    MMK_REQUIRE(spatial >= 1, "mmk_conv8x16_bwd_fused: occupancy query failed");
+    Bwd8Args a;
+    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
+    a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
+    hipLaunchKernelGGL(conv8x16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -536,14 +536,22 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             c.src1 = at(ws, p.a_enc[i].off); c.scale1 = 1.f;
             MMK_TRY(conv(p, h, w, sl, c, stream));
         }
-        MMK_TRY(wgrad(2 * i, at(ws, p.t[i - 1].off), ENC_CH[i - 1], nullptr, 0, at(sc, p.gz_a[i].off), h, w));
         // data gradient accumulates into the skip gradient the decoder wrote for t[i-1]
         void *tgt = at(sc, p.gsk[5 - i].off);             // g_skip[i-1] was written by decoder block j = 4 - (i-1)
-        ConvCall c2;
-        c2.x1 = at(sc, p.gz_a[i].off); c2.C1 = ch; c2.wpack = at(sc, p.packs_t[2 * i]); c2.y1 = tgt; c2.O1 = ENC_CH[i - 1];
-        c2.acc1 = 1;
-        if (i == 1) { c2.src1 = at(ws, p.t[0].off); c2.scale1 = s; }   // t[0] is an activation: factor, then accumulate
-        MMK_TRY(conv(p, h, w, sl, c2, stream));
+        if (i == 1 && fuse_env && sl == 0.f && ch == 16 && ENC_CH[0] == 8 && p.slices[2] > 0 &&
+            mmk_conv3x3_wgrad_slices(16, 8, 8, B, h, w) == p.slices[2]) {
+            // first convolution of block 1: weight gradient and (ReLU-masked, accumulating) data gradient in one launch
+            MMK_TRY(mmk_conv8x16_bwd_fused(at(ws, p.t[0].off), at(sc, p.gz_a[1].off), at(sc, p.packs_t[2]), s, B, h, w, tgt,
+                                           static_cast<float *>(at(sc, p.part[2])), part_used[2] ? 1 : 0, stream));
+            part_used[2] = true;
+        } else {
+            MMK_TRY(wgrad(2 * i, at(ws, p.t[i - 1].off), ENC_CH[i - 1], nullptr, 0, at(sc, p.gz_a[i].off), h, w));
+            ConvCall c2;
+            c2.x1 = at(sc, p.gz_a[i].off); c2.C1 = ch; c2.wpack = at(sc, p.packs_t[2 * i]); c2.y1 = tgt; c2.O1 = ENC_CH[i - 1];
+            c2.acc1 = 1;
+            if (i == 1) { c2.src1 = at(ws, p.t[0].off); c2.scale1 = s; }   // t[0] is an activation: factor, then accumulate
+            MMK_TRY(conv(p, h, w, sl, c2, stream));
+        }
         g_t = tgt;
         // every layer but the three at 640 x 640 has its weight gradients enqueued: reduce them now, under the rest of the chain
         // (the reduction reads all partial slices -- most of them belong to the >= 64-channel layers -- and would otherwise

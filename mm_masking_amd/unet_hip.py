@@ -142,6 +142,16 @@ def conv_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
     return dx, partials
 
 
+def conv8x16_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
+    """dx += ((x > 0) ? scale : 0) * conv_T(g) and the partial weight-gradient slices of an 8 -> 16 convolution in one launch:
+    bit-identical to conv3x3(g, wpack_t, 8, out=dx, relu_src=x, scale=scale, accumulate=True) + conv3x3_wgrad_partial(x, g, 16, partials)."""
+    B, H, W, C = x.shape
+    assert C == 8 and g.shape == (B, H, W, 16) and dx.shape == x.shape
+    _lib.check(_lib.lib().mmk_conv8x16_bwd_fused(_p(x), _p(g), _p(wpack_t), float(scale), B, H, W, _p(dx), _p(partials),
+                                                 1 if accumulate else 0, _lib.stream_ptr(x.device)))
+    return dx, partials
+
+
 def wgrad_unpack_batch(items):
     """One launch for a list of layers.  Each item is either a (9,cout,cin) tensor (atomic form) or a tuple
     (partials, cout, cin[, db_out]) of the partial-sum form; returns the (cout,cin,3,3) gradients (views of

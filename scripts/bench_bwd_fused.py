@@ -21,3 +21,14 @@ for C, H in ((8, 640), (16, 640), (16, 320)):
     def two():
         uh.conv3x3(g, wpt, C, out=dx, relu_src=x, scale=1.05); uh.conv3x3_wgrad_partial(x, g, C, part)
     print("C=%d H=%d  two launches %.1f us   fused %.1f us" % (C, H, timeit(two), timeit(lambda: uh.conv_bwd_fused(x, g, wpt, 1.05, dx, part))))
+
+B, H = 32, 640
+x = (torch.randn(B, H, H, 8, device=dev) * 0.7).clamp_min(0).to(torch.bfloat16)
+g = (torch.randn(B, H, H, 16, device=dev) * 0.3).to(torch.bfloat16)
+w = torch.randn(16, 8, 3, 3, device=dev) / 8
+wpt = uh.pack_weights(w, transposed=True)
+ns = uh.wgrad_slices(16, 8, 8, B, H, H)
+part = uh.partial_buffer(ns, 16, 8, dev); dx = torch.zeros_like(x)
+def two():
+    uh.conv3x3(g, wpt, 8, out=dx, relu_src=x, scale=1.05, accumulate=True); uh.conv3x3_wgrad_partial(x, g, 16, part)
+print("8x16 H=640  two launches %.1f us   fused %.1f us" % (timeit(two), timeit(lambda: uh.conv8x16_bwd_fused(x, g, wpt, 1.05, dx, part))))

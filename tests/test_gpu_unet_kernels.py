@@ -671,3 +671,30 @@ def test_bwd_fused_bit_identical(B, H, W, C):
     torch.cuda.synchronize()
     assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
     assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 37, 45), (1, 640, 640)])
+def test_bwd8x16_fused_bit_identical(B, H, W):
+    """mmk_conv8x16_bwd_fused == the accumulating data-gradient launch (16 -> 8, ReLU source = the layer's 8-channel input
+    activation) + the partial weight-gradient launch of the 8 -> 16 layer, bit for bit."""
+    from mm_masking_amd import unet_hip as uh
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator(device="cpu").manual_seed(23)
+    x = (torch.randn(B, H, W, 8, generator=g0) * 0.7).clamp_min(0).to(dev).to(torch.bfloat16)
+    g = (torch.randn(B, H, W, 16, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
+    skip = (torch.randn(B, H, W, 8, generator=g0) * 0.2).to(dev).to(torch.bfloat16)          # what the decoder left in dx
+    w = (torch.randn(16, 8, 3, 3, generator=g0) / 8.0).to(dev)                                # the 8 -> 16 layer
+    wpt = uh.pack_weights(w, transposed=True)
+    ns = uh.wgrad_slices(16, 8, 8, B, H, W)
+    assert ns > 0
+    ref_dx = skip.clone()
+    ref_part = uh.partial_buffer(ns, 16, 8, dev)
+    uh.conv3x3(g, wpt, 8, out=ref_dx, relu_src=x, scale=1.0 / 0.95, accumulate=True)
+    uh.conv3x3_wgrad_partial(x, g, 16, ref_part)
+    dx = skip.clone()
+    part = torch.full_like(ref_part, 3.0)
+    uh.conv8x16_bwd_fused(x, g, wpt, 1.0 / 0.95, dx, part)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
+    assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
