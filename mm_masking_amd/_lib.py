@@ -108,6 +108,7 @@ def _declare(lib):
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
         "mmk_conv_bwd_fused": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, i32, i32, i32, i32, c_vp, c_vp, i32, c_vp]),
         "mmk_conv8x16_bwd_fused": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, i32, i32, i32, c_vp, c_vp, i32, c_vp]),
+        "mmk_conv16x8_bwd_fused": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, i32, i32, i32, c_vp, c_vp, c_vp, i32, c_vp]),
         "mmk_conv3x3_pool_fusable": (ctypes.c_int32, [i32, i32, i32, i32, i32]),
         "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, f32, c_vp, c_vp]),

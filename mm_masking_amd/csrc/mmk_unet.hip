@@ -1534,6 +1534,8 @@ struct Bwd8Args {
     int B, H, W;
     float *partials;         // [gridDim.x][9*8*8 + 8] partial sums of the weight / bias gradient
     int acc_partials;
+    const bf16 *x2 = nullptr; // conv16x8: second half of the input channels / second output
+    bf16 *dx2 = nullptr;
 };
 
 __global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const Bwd8Args a)
@@ -2150,6 +2152,210 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
         }
         if (wv == 0 && i16 == 0) {
             float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 16 * 8 + co;
+            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
+        }
+    }
+}
+
+// ... and for the second application of the last decoder block's first convolution (16 -> 8 forward on concat(skip, d1)):
+// its data gradient (8 -> 16) produces the skip's and d1's gradients, each masked by its own stored activation -- the two
+// halves of the weight gradient's input: conv3x3_wgrad_kernel<16, 16, true> + conv3x3_ring_kernel<8, 16, 2, true, false, false>.
+__global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const Bwd8Args a)
+{
+    constexpr int PX = 16, PG = 8, NTW = 3, NTT = 9, NS = 3, NT = 4;
+    __shared__ __attribute__((aligned(16))) bf16 x_tile[(HT * WT + 8) * PX];
+    __shared__ __attribute__((aligned(16))) bf16 g_tile[(HT * WT + 8) * PG];
+    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tpi = tiles_x * tiles_y;
+    const int total_tiles = tpi * a.B;
+    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+
+    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    unsigned b_ad[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        int tap = wv + 4 * n;
+        tap = tap > 8 ? 8 : tap;
+        const int ty = tap / 3, tx = tap % 3;
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PX + 4 * pp) * 2);
+    }
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PG + 4 * pp) * 2);
+
+    int d_lane[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int tap = 4 * ks + (lane >> 4);
+        tap = tap > 8 ? 8 : tap;
+        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PG;
+    }
+    int o_pix[NT], s_off[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = 2 * wv + (n >> 1), c = (n & 1) * 16 + (lane & 15);
+        o_pix[n] = r * a.W + c;
+        s_off[n] = ((r + 1) * WT + c + 1) * PX + (lane >> 4) * 4;
+    }
+    bf16 *const o_base = ((lane >> 5) ? a.dx2 : a.dx) + ((lane >> 4) & 1) * 4;      // channels 0-7 -> dx, 8-15 -> dx2
+    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
+
+    constexpr int NX = HT * WT * 2, NG = HT * WT;
+    constexpr int RX = (NX + CONV_THREADS - 1) / CONV_THREADS, RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
+    u32x4 rx[RX], rg[RG];
+    auto load_tile = [&](int t) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tyi = tr / tiles_x;
+        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NX ? gi : NX - 1;
+            const int pix = gi >> 1, half = gi & 1;
+            const int dy = pix / WT - 1, dx = pix % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            const bf16 *src = (half ? a.x2 : a.x) + (long)(pix0 + dy * a.W + dx) * 8;
+            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16);
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int gi = tv + i * CONV_THREADS;
+            gi = gi < NG ? gi : NG - 1;
+            const int dy = gi / WT - 1, dx = gi % WT - 1;
+            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
+            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + (long)(pix0 + dy * a.W + dx) * 8) : &g_zero16);
+        }
+    };
+    auto store_tile = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NX) *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * 8) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gi = tv + i * CONV_THREADS;
+            if (gi < NG) *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * 8) = rg[i];
+        }
+    };
+
+    int t_first, t_step, t_end;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total_tiles + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
+        t_step = (int)gridDim.x >> 3;
+        t_end = min(total_tiles, (xcd + 1) * per_xcd);
+    } else {
+        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
+    }
+    if (t_first < t_end) load_tile(t_first);
+    for (int t = t_first; t < t_end; t += t_step) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        {
+            const int nt = t + t_step;
+            load_tile(nt < t_end ? nt : t);
+        }
+        i32x2 fa[2][2], fb[2][2 * NTW];
+#define BY_ISSUE(R, BUF)                                                                     \
+    {                                                                                        \
+        fa[BUF][0] = tr_read_o<((R) * WT * PG) * 2>(g_ad);                                   \
+        fa[BUF][1] = tr_read_o<((R) * WT * PG + 16 * PG) * 2>(g_ad);                         \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * PX) * 2>(b_ad[n]);                        \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PX + 16 * PX) * 2>(b_ad[n]);          \
+        }                                                                                    \
+    }
+#define BY_CONSUME(BUF)                                                                      \
+    {                                                                                        \
+        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
+    }
+#define BY_STEP(R)                                                                           \
+    {                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((R) + 1 < TH) BY_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        BY_CONSUME((R) & 1);                                                                 \
+    }
+        BY_ISSUE(0, 0);
+        BY_STEP(0) BY_STEP(1) BY_STEP(2) BY_STEP(3) BY_STEP(4) BY_STEP(5) BY_STEP(6) BY_STEP(7)
+#undef BY_STEP
+#undef BY_CONSUME
+#undef BY_ISSUE
+        f32x4 dacc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const bf16 *bl = g_tile + d_lane[ks];
+            bf16x8 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PG);
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
+        }
+        bf16x4 e_src[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) e_src[n] = *reinterpret_cast<const bf16x4 *>(x_tile + s_off[n]);
+#pragma unroll
+        for (int i = 0; i < RX; ++i) asm volatile("" : "+v"(rx[i]));
+#pragma unroll
+        for (int i = 0; i < RG; ++i) asm volatile("" : "+v"(rg[i]));
+        {
+            const int b = t / tpi, tr = t - b * tpi;
+            const int tyi = tr / tiles_x;
+            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+            const int pix0 = (b * a.H + ty0) * a.W + tx0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bool okp = (ty0 + 2 * wv + (n >> 1)) < a.H && (tx0 + (n & 1) * 16 + (lane & 15)) < a.W;
+                bf16x4 outv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(dacc[n][r] + 0.f, -INFINITY);
+                    const float masked = ((float)e_src[n][r] > 0.f) ? v * a.scale : 0.f;
+                    outv[r] = (bf16)(masked + 0.f);
+                }
+                bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(o_base + (long)(pix0 + o_pix[n]) * 8) : reinterpret_cast<bf16x4 *>(g_sink16);
+                *dst = outv;
+            }
+        }
+    }
+
+    // ---- flush (conv3x3_wgrad_kernel<16, 16, true> with COUT = 8, CIN = 16)
+    constexpr size_t pstride = (size_t)9 * 8 * 16 + 8;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = g4 * 4 + rr;
+        if (co >= 8) continue;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int tap = wv + 4 * n;
+            if (tap >= NTT) continue;
+            float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 8 + co) * 16 + i16;
+            *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+        }
+        if (wv == 0 && i16 == 0) {
+            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 8 * 16 + co;
             *d = a.acc_partials ? *d + accb[rr] : accb[rr];
         }
     }
@@ -3603,6 +3809,23 @@ extern "C" int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *
     a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
     hipLaunchKernelGGL(conv8x16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_conv16x8_bwd_fused(const void *x1, const void *x2, const void *g, const void *wpack_t, float scale, int32_t B,
+                                      int32_t H, int32_t W, void *dx1, void *dx2, float *partials, int32_t accumulate, void *stream)
+{
+    MMK_REQUIRE(x1 && x2 && g && wpack_t && dx1 && dx2 && partials, "mmk_conv16x8_bwd_fused: NULL pointer");
+    MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv16x8_bwd_fused: bad shape");
+    MMK_REQUIRE((size_t)B * H * W * 16 < ((size_t)1 << 31), "mmk_conv16x8_bwd_fused: tensor too large for 32-bit offsets");
+    const int spatial = wgrad_slices(8, 16, 8, B, H, W);
+    MMK_REQUIRE(spatial >= 1, "mmk_conv16x8_bwd_fused: occupancy query failed");
+    Bwd8Args a;
+    a.x = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t;
+    a.dx = (bf16 *)dx1; a.dx2 = (bf16 *)dx2; a.scale = scale;
+    a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
+    hipLaunchKernelGGL(conv16x8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

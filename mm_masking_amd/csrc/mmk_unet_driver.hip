@@ -491,13 +491,21 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             c.src1 = at(ws, p.a2[j].off); c.scale1 = 1.f;
             MMK_TRY(conv(p, h, w, sl, c, stream));
         }
-        MMK_TRY(wgrad(k0, skip, cs, at(ws, p.d1[j].off), cs, at(sc, p.gz_a2[j].off), h, w));
-        ConvCall c2;       // one pass, two outputs: the skip's gradient and the first application's output gradient
-        c2.x1 = at(sc, p.gz_a2[j].off); c2.C1 = cs; c2.wpack = at(sc, p.packs_t[k0]);
-        c2.y1 = at(sc, p.gsk[j].off); c2.O1 = cs; c2.scale1 = s;
-        c2.src1 = (j == 4) ? skip : nullptr;   // dec4's skip is the post-dropout activation of encoder block 0
-        c2.y2 = at(sc, p.gz_d1[j].off); c2.O2 = cs; c2.src2 = at(ws, p.d1[j].off); c2.scale2 = s;
-        MMK_TRY(conv(p, h, w, sl, c2, stream));
+        if (j == 4 && fuse_env && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 8, B, h, w) == p.slices[k0]) {
+            // last decoder block: both halves of the data gradient are masked by the two halves of the weight gradient's input
+            MMK_TRY(mmk_conv16x8_bwd_fused(skip, at(ws, p.d1[j].off), at(sc, p.gz_a2[j].off), at(sc, p.packs_t[k0]), s, B, h, w,
+                                           at(sc, p.gsk[j].off), at(sc, p.gz_d1[j].off), static_cast<float *>(at(sc, p.part[k0])),
+                                           part_used[k0] ? 1 : 0, stream));
+            part_used[k0] = true;
+        } else {
+            MMK_TRY(wgrad(k0, skip, cs, at(ws, p.d1[j].off), cs, at(sc, p.gz_a2[j].off), h, w));
+            ConvCall c2;       // one pass, two outputs: the skip's gradient and the first application's output gradient
+            c2.x1 = at(sc, p.gz_a2[j].off); c2.C1 = cs; c2.wpack = at(sc, p.packs_t[k0]);
+            c2.y1 = at(sc, p.gsk[j].off); c2.O1 = cs; c2.scale1 = s;
+            c2.src1 = (j == 4) ? skip : nullptr;   // dec4's skip is the post-dropout activation of encoder block 0
+            c2.y2 = at(sc, p.gz_d1[j].off); c2.O2 = cs; c2.src2 = at(ws, p.d1[j].off); c2.scale2 = s;
+            MMK_TRY(conv(p, h, w, sl, c2, stream));
+        }
         // first application
         if (fuse8) {
             MMK_TRY(bwd_fused(k1, cs, at(ws, p.a1[j].off), at(sc, p.gz_d1[j].off), at(sc, p.gz_a1[j].off), h, w));

@@ -152,6 +152,17 @@ def conv8x16_bwd_fused(x, g, wpack_t, scale, dx, partials, accumulate=False):
     return dx, partials
 
 
+def conv16x8_bwd_fused(x1, x2, g, wpack_t, scale, dx1, dx2, partials, accumulate=False):
+    """Backward of a 16 -> 8 convolution on concat(x1, x2) in one launch: the two halves of its data gradient, each masked by its
+    own input activation, and the partial weight-gradient slices; bit-identical to conv3x3(g, wpack_t, 16, out=dx1, out2=dx2,
+    split=8, relu_src=x1, relu_src2=x2, scale=scale2=scale) + conv3x3_wgrad_partial(x1, g, 8, partials, x2=x2)."""
+    B, H, W, C = x1.shape
+    assert C == 8 and x2.shape == x1.shape and g.shape == x1.shape and dx1.shape == x1.shape and dx2.shape == x1.shape
+    _lib.check(_lib.lib().mmk_conv16x8_bwd_fused(_p(x1), _p(x2), _p(g), _p(wpack_t), float(scale), B, H, W, _p(dx1), _p(dx2),
+                                                 _p(partials), 1 if accumulate else 0, _lib.stream_ptr(x1.device)))
+    return dx1, dx2, partials
+
+
 def wgrad_unpack_batch(items):
     """One launch for a list of layers.  Each item is either a (9,cout,cin) tensor (atomic form) or a tuple
     (partials, cout, cin[, db_out]) of the partial-sum form; returns the (cout,cin,3,3) gradients (views of

@@ -698,3 +698,31 @@ def test_bwd8x16_fused_bit_identical(B, H, W):
     torch.cuda.synchronize()
     assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
     assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 37, 45), (1, 640, 640)])
+def test_bwd16x8_fused_bit_identical(B, H, W):
+    """mmk_conv16x8_bwd_fused == the two-output data-gradient launch (8 -> 16, each half masked by its own input activation)
+    + the partial weight-gradient launch of the 16 -> 8 layer on concat(x1, x2), bit for bit."""
+    from mm_masking_amd import unet_hip as uh
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator(device="cpu").manual_seed(29)
+    x1 = (torch.randn(B, H, W, 8, generator=g0) * 0.7).clamp_min(0).to(dev).to(torch.bfloat16)
+    x2 = (torch.randn(B, H, W, 8, generator=g0) * 0.5).clamp_min(0).to(dev).to(torch.bfloat16)
+    g = (torch.randn(B, H, W, 8, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
+    w = (torch.randn(8, 16, 3, 3, generator=g0) / 8.0).to(dev)                                # the 16 -> 8 layer
+    wpt = uh.pack_weights(w, transposed=True)
+    ns = uh.wgrad_slices(8, 16, 8, B, H, W)
+    assert ns > 0
+    r1, r2 = torch.empty_like(x1), torch.empty_like(x1)
+    ref_part = uh.partial_buffer(ns, 8, 16, dev)
+    uh.conv3x3(g, wpt, 16, out=r1, out2=r2, split=8, relu_src=x1, scale=1.0 / 0.95, relu_src2=x2, scale2=1.0 / 0.95)
+    uh.conv3x3_wgrad_partial(x1, g, 8, ref_part, x2=x2)
+    d1, d2 = torch.full_like(x1, 5.0), torch.full_like(x1, 6.0)
+    part = torch.full_like(ref_part, 3.0)
+    uh.conv16x8_bwd_fused(x1, x2, g, wpt, 1.0 / 0.95, d1, d2, part)
+    torch.cuda.synchronize()
+    assert torch.equal(d1.view(torch.int16), r1.view(torch.int16))
+    assert torch.equal(d2.view(torch.int16), r2.view(torch.int16))
+    assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
