@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_masking_amd import unet_hip as uh
 dev = torch.device("cuda:0")
 def timeit(fn, n=20):

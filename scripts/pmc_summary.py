@@ -15,7 +15,7 @@ dur = {}
 for name, disp, cnt, val, d in rows:
     if flt and flt not in name:
         continue
-    short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
     per[(short, disp)][cnt] += val
     dur[(short, disp)] = d
 out = collections.defaultdict(lambda: collections.defaultdict(list))
