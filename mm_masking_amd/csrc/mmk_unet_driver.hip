@@ -576,9 +576,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         c.src1 = at(ws, p.a_enc[0].off); c.scale1 = 1.f;
         MMK_TRY(conv(p, p.H, p.W, sl, c, stream));
     }
-    MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1], stream));
-    // ---- parameter gradients of the first three 3x3 layers (the rest was reduced while the 640 x 640 levels were still running)
+    // ---- parameter gradients of the first three 3x3 layers (the rest was reduced while the 640 x 640 levels were still
+    // running): on the weight-gradient stream, beside the first layer's weight gradient
     MMK_TRY(unpack(1, 3));
+    MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1], stream));
     if (ss) {       // join: the caller's stream continues only after every gradient is written
         MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
         MMK_CHECK_HIP(hipStreamWaitEvent(st, ss->join, 0));
