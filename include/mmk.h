@@ -277,7 +277,9 @@ int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *wpack_t, fl
  * split the same way and masked by the two inputs: dx1 = ((x1 > 0) ? scale : 0) * conv_T(g)[0:8], dx2 likewise with x2 and
  * channels 8:16 (second application of the last decoder block's first convolution), as mmk_conv3x3 with two output parts,
  * relu_src = x1 / x2, and the partial slices of mmk_conv3x3_wgrad_partial(x1, x2, 8, 8, g, 8, ...):
- * mmk_conv3x3_wgrad_slices(8, 16, 8, B, H, W) slices of 9*8*16 + 8 floats.  g: (B,H,W,8). */
+ * mmk_conv3x3_wgrad_slices(8, 16, 8, B, H, W) slices of 9*8*16 + 8 floats.  g: (B,H,W,8).
+ * x2 = dx2 = NULL: x1 is ONE (B,H,W,16) input and dx1 ONE (B,H,W,16) output without ReLU source (scale unused):
+ * dx1 = conv_T(g), as mmk_conv3x3 without epilogue operands + mmk_conv3x3_wgrad_partial(x1, NULL, 16, 0, g, 8, ...). */
 int mmk_conv16x8_bwd_fused(const void *x1, const void *x2, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H,
                            int32_t W, void *dx1, void *dx2, float *partials, int32_t accumulate, void *stream);
 /* n layers in one launch (no accumulation): dW[i] (cout,cin,3,3) = src[i] (9,cout,cin) when slices is NULL or

@@ -2204,7 +2204,12 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const 
         o_pix[n] = r * a.W + c;
         s_off[n] = ((r + 1) * WT + c + 1) * PX + (lane >> 4) * 4;
     }
-    bf16 *const o_base = ((lane >> 5) ? a.dx2 : a.dx) + ((lane >> 4) & 1) * 4;      // channels 0-7 -> dx, 8-15 -> dx2
+    // two 8-channel halves (x | x2 in, dx | dx2 out, each output half masked by its input half), or -- x2 = dx2 = null -- one
+    // 16-channel input and one unmasked 16-channel output (a data gradient without ReLU source: the first application of
+    // the decoder convolution, whose input is the up-sampled tensor)
+    const bool split = a.x2 != nullptr;
+    bf16 *const o_base = split ? ((lane >> 5) ? a.dx2 : a.dx) + ((lane >> 4) & 1) * 4 : a.dx + (lane >> 4) * 4;
+    const int o_stride = split ? 8 : 16;
     for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
 
     constexpr int NX = HT * WT * 2, NG = HT * WT;
@@ -2224,7 +2229,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const 
             const int pix = gi >> 1, half = gi & 1;
             const int dy = pix / WT - 1, dx = pix % WT - 1;
             const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            const bf16 *src = (half ? a.x2 : a.x) + (long)(pix0 + dy * a.W + dx) * 8;
+            const long po = pix0 + dy * a.W + dx;
+            const bf16 *src = split ? (half ? a.x2 : a.x) + po * 8 : a.x + po * 16 + half * 8;
             rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16);
         }
 #pragma unroll
@@ -2333,9 +2339,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(dacc[n][r] + 0.f, -INFINITY);
                     const float masked = ((float)e_src[n][r] > 0.f) ? v * a.scale : 0.f;
-                    outv[r] = (bf16)(masked + 0.f);
+                    outv[r] = (bf16)(split ? masked + 0.f : v);
                 }
-                bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(o_base + (long)(pix0 + o_pix[n]) * 8) : reinterpret_cast<bf16x4 *>(g_sink16);
+                bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(o_base + (long)(pix0 + o_pix[n]) * o_stride) : reinterpret_cast<bf16x4 *>(g_sink16);
                 *dst = outv;
             }
         }
@@ -3816,7 +3822,8 @@ extern "C" int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *
 extern "C" int mmk_conv16x8_bwd_fused(const void *x1, const void *x2, const void *g, const void *wpack_t, float scale, int32_t B,
                                       int32_t H, int32_t W, void *dx1, void *dx2, float *partials, int32_t accumulate, void *stream)
 {
-    MMK_REQUIRE(x1 && x2 && g && wpack_t && dx1 && dx2 && partials, "mmk_conv16x8_bwd_fused: NULL pointer");
+    MMK_REQUIRE(x1 && g && wpack_t && dx1 && partials, "mmk_conv16x8_bwd_fused: NULL pointer");
+    MMK_REQUIRE((x2 == nullptr) == (dx2 == nullptr), "mmk_conv16x8_bwd_fused: x2 and dx2 go together (both NULL: one 16-channel input / unmasked output)");
     MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv16x8_bwd_fused: bad shape");
     MMK_REQUIRE((size_t)B * H * W * 16 < ((size_t)1 << 31), "mmk_conv16x8_bwd_fused: tensor too large for 32-bit offsets");
     const int spatial = wgrad_slices(8, 16, 8, B, H, W);

@@ -516,10 +516,18 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             c3.src1 = at(ws, p.a1[j].off); c3.scale1 = 1.f;
             MMK_TRY(conv(p, h, w, sl, c3, stream));
         }
-        MMK_TRY(wgrad(k0, at(ws, p.u[j].off), 2 * cs, nullptr, 0, at(sc, p.gz_a1[j].off), h, w));
-        ConvCall c4;
-        c4.x1 = at(sc, p.gz_a1[j].off); c4.C1 = cs; c4.wpack = at(sc, p.packs_t[k0]); c4.y1 = at(sc, p.g_u[j].off); c4.O1 = 2 * cs;
-        MMK_TRY(conv(p, h, w, sl, c4, stream));
+        if (j == 4 && fuse_env && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 16, B, h, w) == p.slices[k0]) {
+            // (first application: the input is the up-sampled tensor, no ReLU source -- the launch shares the output gradient)
+            MMK_TRY(mmk_conv16x8_bwd_fused(at(ws, p.u[j].off), nullptr, at(sc, p.gz_a1[j].off), at(sc, p.packs_t[k0]), 1.f, B, h, w,
+                                           at(sc, p.g_u[j].off), nullptr, static_cast<float *>(at(sc, p.part[k0])),
+                                           part_used[k0] ? 1 : 0, stream));
+            part_used[k0] = true;
+        } else {
+            MMK_TRY(wgrad(k0, at(ws, p.u[j].off), 2 * cs, nullptr, 0, at(sc, p.gz_a1[j].off), h, w));
+            ConvCall c4;
+            c4.x1 = at(sc, p.gz_a1[j].off); c4.C1 = cs; c4.wpack = at(sc, p.packs_t[k0]); c4.y1 = at(sc, p.g_u[j].off); c4.O1 = 2 * cs;
+            MMK_TRY(conv(p, h, w, sl, c4, stream));
+        }
         if (j > 0) {
             const Tens &pd2 = p.d2[j - 1];
             MMK_TRY(mmk_upsample_bwd(at(sc, p.g_u[j].off), B, pd2.h, pd2.w, 2 * cs, h, w, at(ws, pd2.off), s, sl, at(sc, p.gz_up[j].off),

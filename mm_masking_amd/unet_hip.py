@@ -157,7 +157,10 @@ def conv16x8_bwd_fused(x1, x2, g, wpack_t, scale, dx1, dx2, partials, accumulate
     own input activation, and the partial weight-gradient slices; bit-identical to conv3x3(g, wpack_t, 16, out=dx1, out2=dx2,
     split=8, relu_src=x1, relu_src2=x2, scale=scale2=scale) + conv3x3_wgrad_partial(x1, g, 8, partials, x2=x2)."""
     B, H, W, C = x1.shape
-    assert C == 8 and x2.shape == x1.shape and g.shape == x1.shape and dx1.shape == x1.shape and dx2.shape == x1.shape
+    if x2 is None:        # one 16-channel input, one unmasked 16-channel output
+        assert C == 16 and dx2 is None and g.shape == (B, H, W, 8) and dx1.shape == x1.shape
+    else:
+        assert C == 8 and x2.shape == x1.shape and g.shape == x1.shape and dx1.shape == x1.shape and dx2.shape == x1.shape
     _lib.check(_lib.lib().mmk_conv16x8_bwd_fused(_p(x1), _p(x2), _p(g), _p(wpack_t), float(scale), B, H, W, _p(dx1), _p(dx2),
                                                  _p(partials), 1 if accumulate else 0, _lib.stream_ptr(x1.device)))
     return dx1, dx2, partials

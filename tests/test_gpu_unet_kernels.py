@@ -726,3 +726,29 @@ def test_bwd16x8_fused_bit_identical(B, H, W):
     assert torch.equal(d1.view(torch.int16), r1.view(torch.int16))
     assert torch.equal(d2.view(torch.int16), r2.view(torch.int16))
     assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 37, 45), (1, 640, 640)])
+def test_bwd16x8_fused_plain_bit_identical(B, H, W):
+    """The same launch without ReLU source (one 16-channel input, one unmasked 16-channel output), accumulating into the
+    slices of an earlier application: == mmk_conv3x3 (no epilogue operands) + mmk_conv3x3_wgrad_partial(accumulate)."""
+    from mm_masking_amd import unet_hip as uh
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator(device="cpu").manual_seed(31)
+    x = (torch.randn(B, H, W, 16, generator=g0) * 0.7).to(dev).to(torch.bfloat16)
+    g = (torch.randn(B, H, W, 8, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
+    w = (torch.randn(8, 16, 3, 3, generator=g0) / 8.0).to(dev)
+    wpt = uh.pack_weights(w, transposed=True)
+    ns = uh.wgrad_slices(8, 16, 16, B, H, W)
+    assert ns > 0 and ns == uh.wgrad_slices(8, 16, 8, B, H, W)
+    ref_part = (torch.randn(ns, 9 * 8 * 16 + 8, generator=g0)).to(dev)
+    part = ref_part.clone()
+    ref_dx = torch.empty_like(x)
+    uh.conv3x3(g, wpt, 16, out=ref_dx)
+    uh.conv3x3_wgrad_partial(x, g, 8, ref_part, accumulate=True)
+    dx = torch.full_like(x, 5.0)
+    uh.conv16x8_bwd_fused(x, None, g, wpt, 1.0, dx, None, part, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(torch.int16), ref_dx.view(torch.int16))
+    assert torch.equal(part.view(torch.int32), ref_part.view(torch.int32))
