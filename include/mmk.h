@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 200 /* 0.2.0 */
+#define MMK_VERSION 210 /* 0.2.1: + mmk_conv_bwd_fused, mmk_conv8x16_bwd_fused, mmk_conv16x8_bwd_fused */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)

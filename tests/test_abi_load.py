@@ -27,7 +27,7 @@ def test_header_symbols_exported(L):
     for n in sorted(names):
         assert hasattr(L, n), "symbol %s declared in mmk.h is not exported" % n
     assert names == set(_lib.EXPORTED.keys()), names ^ set(_lib.EXPORTED.keys())
-    assert L.mmk_version() == 200
+    assert L.mmk_version() == 210
 
 
 def test_host_side_argument_checks(L):
