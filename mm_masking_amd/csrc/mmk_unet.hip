@@ -1517,33 +1517,46 @@ int launch_wgrad(const WgradArgs &a, hipStream_t st)
 
 
 // ------------------------------------------------------------------------------------------
-// Backward pass of an 8 -> 8 "second convolution of a block" in ONE kernel.  Its data gradient (input: the output gradient g,
-// epilogue operand: the block's stored activation x as ReLU source) and its weight gradient (inputs: x and g) read the same
-// two tensors; as two kernels, on two streams, each of them streams both tensors from HBM and the pair takes as long side by
-// side as one after the other (both are bandwidth-bound at 640 x 640).  Here a block stages the halo tiles of x and of g once:
-// the weight-gradient contraction reads x with its halo and the interior of g (conv3x3_wgrad_kernel<8, 16, true>, same
-// fragment reads, same row order, same persistent tile walk and partial slices), the data gradient reads g with its halo and
-// takes the ReLU source from the interior of the x tile in LDS (conv3x3_ring_kernel<8, 16, ., true, false, true>: same
-// k-steps and the same 8-channel epilogue) -- 630 MB per launch at B = 32 instead of 1 050, results bit-identical to the
-// two-kernel path (tests/test_gpu_unet_kernels.py::test_bwd8_fused_bit_identical).
-struct Bwd8Args {
-    const bf16 *x, *g;       // (B,H,W,8) each
+// Backward pass of a thin layer in ONE kernel, for the layers whose data gradient takes the layer's own input as ReLU
+// source.  The data gradient (input: the output gradient g; epilogue operand: a stored activation x as ReLU source) and the
+// weight gradient (inputs: x and g) then read the same two tensors; as two kernels, on two streams, each of them streams
+// both from HBM, and at 640 x 640 the pair takes as long side by side as one after the other (both are bandwidth-bound).
+// Here a block stages the halo tiles of x and of g once: the weight-gradient contraction reads x with its halo and the
+// interior of g (conv3x3_wgrad_kernel: same fragment reads, same row order, same persistent tile walk and partial slices),
+// the data gradient reads g with its halo and takes the ReLU source from the interior of the x tile in LDS
+// (conv3x3_ring_kernel: same k-steps, same epilogue arithmetic) -- 630 MB per launch for 8 -> 8 channels at B = 32,
+// 640 x 640, instead of 1 050, and results bit-identical to the two-kernel path (tests/test_gpu_unet_kernels.py::
+// test_bwd*_fused_*).  CX = channels of x = output channels of the data gradient = input channels of the weight gradient;
+// CG = channels of g.  Instantiated for the four pairs of the reference network's 640 x 640 / 320 x 320 levels:
+//   <8, 8>, <16, 16>  second convolution of a block (wgrad<CX, 16, CX == 8> + ring<CX, 16, ., true, false, CX == 8>)
+//   <8, 16>           first convolution of encoder block 1: the data gradient also ADDS to what dx holds (the skip gradient)
+//   <16, 8>           first convolution of the last decoder block: input concat(x | x2) with the data gradient's halves
+//                     dx | dx2 masked by x | x2 (second application), or one 16-channel input and one unmasked output
+//                     (first application: the input is the up-sampled tensor, which is no ReLU source)
+struct BwdFusedArgs {
+    const bf16 *x, *x2;      // (B,H,W,CX), or two (B,H,W,8) halves when x2 is set
+    const bf16 *g;           // (B,H,W,CG)
     const bf16 *wpack_t;     // the data-gradient operator's packed weights (mmk_conv3x3_pack_weights, transposed = 1)
-    bf16 *dx;                // (B,H,W,8): ((x > 0) ? scale : 0) * conv_T(g)
+    bf16 *dx, *dx2;          // (B,H,W,CX), or two halves
     float scale;
+    int masked;              // dx = ((x > 0) ? scale : 0) * conv_T(g); 0: dx = conv_T(g)
+    int accumulate_dx;       // dx += ... (CX = 8)
     int B, H, W;
-    float *partials;         // [gridDim.x][9*8*8 + 8] partial sums of the weight / bias gradient
+    float *partials;         // [gridDim.x][9*CG*CX + CG] partial sums of the weight / bias gradient
     int acc_partials;
-    const bf16 *x2 = nullptr; // conv16x8: second half of the input channels / second output
-    bf16 *dx2 = nullptr;
 };
 
-__global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const Bwd8Args a)
+template <int CX, int CG>
+__global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdFusedArgs a)
 {
-    constexpr int PK = 8, NTW = 2, NTT = 5, NS = 3, NT = 4;
-    constexpr int TILE = (HT * WT + 8) * PK;
-    __shared__ __attribute__((aligned(16))) bf16 x_tile[TILE];
-    __shared__ __attribute__((aligned(16))) bf16 g_tile[TILE];
+    static_assert((CX == 8 || CX == 16) && (CG == 8 || CG == 16), "thin layers");
+    constexpr int NTT = CX == 8 ? 5 : 9;          // weight gradient: 16-column tiles of (tap, ci)
+    constexpr int NTW = (NTT + 3) / 4;            // ... per wave
+    constexpr int NS = CG == 8 ? 3 : 5;           // data gradient: k-steps (4 taps x 8 channels | 2 taps x 16 channels)
+    constexpr int NT = 4;
+    constexpr int GX = CX / 8, GG = CG / 8;       // 16-byte granules per pixel
+    __shared__ __attribute__((aligned(16))) bf16 x_tile[(HT * WT + 8) * CX];
+    __shared__ __attribute__((aligned(16))) bf16 g_tile[(HT * WT + 8) * CG];
     __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1552,8 +1565,9 @@ __global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const 
     const int tpi = tiles_x * tiles_y;
     const int total_tiles = tpi * a.B;
     const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
+    const bool split = a.x2 != nullptr;
 
-    // ---- weight-gradient side (conv3x3_wgrad_kernel<8, 16, true>)
+    // ---- weight-gradient side (conv3x3_wgrad_kernel<CX, 16, CG == 8>)
     f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1564,436 +1578,43 @@ __global__ __launch_bounds__(CONV_THREADS, 6) void conv8_bwd_fused_kernel(const 
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         const int nt = wv + 4 * n;
-        int tap = 2 * nt + (pp >> 1);
-        const int col = 4 * (pp & 1);
+        int tap = CX == 8 ? 2 * nt + (pp >> 1) : nt;
+        const int col = CX == 8 ? 4 * (pp & 1) : 4 * pp;
         tap = tap > 8 ? 8 : tap;
         const int ty = tap / 3, tx = tap % 3;
-        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PK + col) * 2);
+        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * CX + col) * 2);
     }
     // (the g tile carries its halo here: the interior starts one row and one column in)
-    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PK + 4 * pp) * 2);
+    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * CG + 4 * pp) * 2);
 
-    // ---- data-gradient side (conv3x3_ring_kernel<8, 16, ., true, false, true>)
+    // ---- data-gradient side (conv3x3_ring_kernel<CG, 16, ., true, false, CX == 8>)
     int d_lane[NS];
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
-        int tap = 4 * ks + (lane >> 4);
+        int tap = CG == 8 ? 4 * ks + (lane >> 4) : 2 * ks + (lane >> 5);
+        const int ch = CG == 8 ? 0 : 8 * ((lane >> 4) & 1);
         tap = tap > 8 ? 8 : tap;
-        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PK;
+        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * CG + ch;
     }
+    // CX = 8: after the lane exchange a lane holds the 8 channels of pixel (lrow8, lcol8); CX = 16: the lane's 4 channels
+    // of pixel (2 wv + n/2, 16 (n&1) + lane%16) per n-tile
     const int n8 = lane >> 4;
     const int lrow8 = 2 * wv + (n8 >> 1), lcol8 = (n8 & 1) * 16 + (lane & 15);
     const int lpix8 = lrow8 * a.W + lcol8;
-    const int s_off8 = ((lrow8 + 1) * WT + lcol8 + 1) * PK;      // the lane's pixel in the x tile (ReLU source)
-    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
-
-    constexpr int NIN = HT * WT;                     // granules (8 channels = one granule per pixel) of a halo tile
-    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
-    u32x4 rx[RIN], rg[RIN];
-    auto load_tile = [&](int t) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-        const int pix0 = (b * a.H + ty0) * a.W + tx0;
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            int gi = tv + i * CONV_THREADS;
-            gi = gi < NIN ? gi : NIN - 1;
-            const int dy = gi / WT - 1, dx = gi % WT - 1;
-            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            const long p = (long)(pix0 + dy * a.W + dx) * 8;
-            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + p) : &g_zero16);
-            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + p) : &g_zero16);
-        }
-    };
-    auto store_tile = [&]() {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            const int gi = tv + i * CONV_THREADS;
-            if (gi < NIN) {
-                *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * PK) = rx[i];
-                *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * PK) = rg[i];
-            }
-        }
-    };
-
-    int t_first, t_step, t_end;
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (total_tiles + 7) / 8;
-        const int xcd = blockIdx.x & 7;
-        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
-        t_step = (int)gridDim.x >> 3;
-        t_end = min(total_tiles, (xcd + 1) * per_xcd);
-    } else {
-        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
-    }
-    if (t_first < t_end) load_tile(t_first);
-    for (int t = t_first; t < t_end; t += t_step) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);
-        }
-        // ---- weight gradient: tile rows 0..7, the fragments of row r+1 in flight while row r is consumed
-        i32x2 fa[2][2], fb[2][2 * NTW];
-#define B8_ISSUE(R, BUF)                                                                     \
-    {                                                                                        \
-        fa[BUF][0] = tr_read_o<((R) * WT * PK) * 2>(g_ad);                                   \
-        fa[BUF][1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(g_ad);                         \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
-            fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                        \
-            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(b_ad[n]);          \
-        }                                                                                    \
-    }
-#define B8_CONSUME(BUF)                                                                      \
-    {                                                                                        \
-        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
-    }
-#define B8_STEP(R)                                                                           \
-    {                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        if ((R) + 1 < TH) B8_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        B8_CONSUME((R) & 1);                                                                 \
-    }
-        B8_ISSUE(0, 0);
-        B8_STEP(0) B8_STEP(1) B8_STEP(2) B8_STEP(3) B8_STEP(4) B8_STEP(5) B8_STEP(6) B8_STEP(7)
-        static_assert(TH == 8, "B8_STEP expansion above covers 8 tile rows");
-#undef B8_STEP
-#undef B8_CONSUME
-#undef B8_ISSUE
-        // ---- data gradient of the tile
-        f32x4 dacc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-            const bf16 *bl = g_tile + d_lane[ks];
-            bf16x8 bf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PK);
-            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
-        }
-        const u32x4 e8_src = *reinterpret_cast<const u32x4 *>(x_tile + s_off8);
-        // the next tile's operands have had the MFMA work to arrive: take delivery in front of this tile's stores
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            asm volatile("" : "+v"(rx[i]));
-            asm volatile("" : "+v"(rg[i]));
-        }
-        {
-            const int b = t / tpi, tr = t - b * tpi;
-            const int tyi = tr / tiles_x;
-            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-            const int pix0 = (b * a.H + ty0) * a.W + tx0;
-            float v8[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[0][r]), __float_as_uint(dacc[1][r]), false, false);
-                const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[2][r]), __float_as_uint(dacc[3][r]), false, false);
-                const auto lo = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
-                const auto hi = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
-                v8[r] = __uint_as_float(lo[0]);
-                v8[4 + r] = __uint_as_float(hi[0]);
-            }
-            float sv[8];
-            unpack8(e8_src, sv);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                // (the two additions of zero are the ring kernel's bias and accumulate-target additions: they turn -0 into +0)
-                const float v = fmaxf(v8[r] + 0.f, -INFINITY);
-                const float masked = (sv[r] > 0.f) ? v * a.scale : 0.f;
-                v8[r] = masked + 0.f;
-            }
-            const bool ok8 = (ty0 + lrow8) < a.H && (tx0 + lcol8) < a.W;
-            u32x4 *dst8 = ok8 ? reinterpret_cast<u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : reinterpret_cast<u32x4 *>(g_sink16);
-            *dst8 = pack8(v8);
-        }
-    }
-
-    // ---- flush the block's partial slice (as conv3x3_wgrad_kernel<8, 16, true> with COUT = CIN = 8)
-    constexpr size_t pstride = (size_t)9 * 8 * 8 + 8;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int co = g4 * 4 + rr;
-        if (co >= 8) continue;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int nt = wv + 4 * n;
-            if (nt >= NTT) continue;
-            const int tap = 2 * nt + (i16 >> 3), ci = i16 & 7;
-            if (tap < 9) {
-                float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 8 + co) * 8 + ci;
-                *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
-            }
-        }
-        if (wv == 0 && i16 == 0) {
-            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 8 * 8 + co;
-            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
-        }
-    }
-}
-
-// The same for a 16 -> 16 layer: conv3x3_wgrad_kernel<16, 16, false> + conv3x3_ring_kernel<16, 16, ., true, false, false>
-// (9 weight-gradient column tiles, 5 data-gradient k-steps of two taps, 4 channels of a pixel per lane in the epilogue).
-__global__ __launch_bounds__(CONV_THREADS) void conv16_bwd_fused_kernel(const Bwd8Args a)
-{
-    constexpr int C = 16, PK = 16, NTW = 3, NTT = 9, NS = 5, NT = 4;
-    constexpr int TILE = (HT * WT + 8) * PK;
-    __shared__ __attribute__((aligned(16))) bf16 x_tile[TILE];
-    __shared__ __attribute__((aligned(16))) bf16 g_tile[TILE];
-    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int tpi = tiles_x * tiles_y;
-    const int total_tiles = tpi * a.B;
-    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-
-    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-    unsigned b_ad[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        int tap = wv + 4 * n;
-        tap = tap > 8 ? 8 : tap;
-        const int ty = tap / 3, tx = tap % 3;
-        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PK + 4 * pp) * 2);
-    }
-    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PK + 4 * pp) * 2);
-
-    int d_lane[NS];
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-        int tap = 2 * ks + (lane >> 5);
-        const int ch = 8 * ((lane >> 4) & 1);
-        tap = tap > 8 ? 8 : tap;
-        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PK + ch;
-    }
-    int o_pix[NT], s_off[NT];                         // the lane's 4 channels of pixel (2 wv + n/2, 16 (n&1) + lane%16)
+    const int s_off8 = ((lrow8 + 1) * WT + lcol8 + 1) * CX;      // the lane's pixel in the x tile (ReLU source)
+    int o_pix[NT], s_off[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int r = 2 * wv + (n >> 1), c = (n & 1) * 16 + (lane & 15);
         o_pix[n] = r * a.W + c;
-        s_off[n] = ((r + 1) * WT + c + 1) * PK + (lane >> 4) * 4;
+        s_off[n] = ((r + 1) * WT + c + 1) * CX + (lane >> 4) * 4;
     }
+    bf16 *const o_base = (a.dx2 != nullptr) ? ((lane >> 5) ? a.dx2 : a.dx) + ((lane >> 4) & 1) * 4 : a.dx + (lane >> 4) * 4;
+    const int o_stride = (a.dx2 != nullptr) ? 8 : 16;
     for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
 
-    constexpr int GPP = C / 8;
-    constexpr int NIN = HT * WT * GPP;
-    constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
-    u32x4 rx[RIN], rg[RIN];
-    auto load_tile = [&](int t) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-        const int pix0 = (b * a.H + ty0) * a.W + tx0;
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            int gi = tv + i * CONV_THREADS;
-            gi = gi < NIN ? gi : NIN - 1;
-            const int pix = gi / GPP, gc = gi % GPP;
-            const int dy = pix / WT - 1, dx = pix % WT - 1;
-            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            const long p = (long)(pix0 + dy * a.W + dx) * C + gc * 8;
-            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + p) : &g_zero16);
-            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + p) : &g_zero16);
-        }
-    };
-    auto store_tile = [&]() {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            const int gi = tv + i * CONV_THREADS;
-            if (gi < NIN) {
-                *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * 8) = rx[i];       // (granule gi = pixel gi / 2, half gi % 2)
-                *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * 8) = rg[i];
-            }
-        }
-    };
-
-    int t_first, t_step, t_end;
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (total_tiles + 7) / 8;
-        const int xcd = blockIdx.x & 7;
-        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
-        t_step = (int)gridDim.x >> 3;
-        t_end = min(total_tiles, (xcd + 1) * per_xcd);
-    } else {
-        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
-    }
-    if (t_first < t_end) load_tile(t_first);
-    for (int t = t_first; t < t_end; t += t_step) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);
-        }
-        i32x2 fa[2][2], fb[2][2 * NTW];
-#define B16_ISSUE(R, BUF)                                                                    \
-    {                                                                                        \
-        fa[BUF][0] = tr_read_o<((R) * WT * PK) * 2>(g_ad);                                   \
-        fa[BUF][1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(g_ad);                         \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
-            fb[BUF][2 * n] = tr_read_o<((R) * WT * PK) * 2>(b_ad[n]);                        \
-            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PK + 16 * PK) * 2>(b_ad[n]);          \
-        }                                                                                    \
-    }
-#define B16_CONSUME(BUF)                                                                     \
-    {                                                                                        \
-        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
-    }
-#define B16_STEP(R)                                                                          \
-    {                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        if ((R) + 1 < TH) B16_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        B16_CONSUME((R) & 1);                                                                \
-    }
-        B16_ISSUE(0, 0);
-        B16_STEP(0) B16_STEP(1) B16_STEP(2) B16_STEP(3) B16_STEP(4) B16_STEP(5) B16_STEP(6) B16_STEP(7)
-#undef B16_STEP
-#undef B16_CONSUME
-#undef B16_ISSUE
-        f32x4 dacc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-            const bf16 *bl = g_tile + d_lane[ks];
-            bf16x8 bf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PK);
-            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
-        }
-        bf16x4 e_src[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) e_src[n] = *reinterpret_cast<const bf16x4 *>(x_tile + s_off[n]);
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            asm volatile("" : "+v"(rx[i]));
-            asm volatile("" : "+v"(rg[i]));
-        }
-        {
-            const int b = t / tpi, tr = t - b * tpi;
-            const int tyi = tr / tiles_x;
-            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-            const int pix0 = (b * a.H + ty0) * a.W + tx0;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const bool okp = (ty0 + 2 * wv + (n >> 1)) < a.H && (tx0 + (n & 1) * 16 + (lane & 15)) < a.W;
-                bf16x4 outv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(dacc[n][r] + 0.f, -INFINITY);          // (the ring kernel's bias addition: -0 -> +0)
-                    const float masked = ((float)e_src[n][r] > 0.f) ? v * a.scale : 0.f;
-                    outv[r] = (bf16)(masked + 0.f);                               // (... and its accumulate-target addition)
-                }
-                bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(a.dx + ((long)(pix0 + o_pix[n]) * C + (lane >> 4) * 4))
-                                  : reinterpret_cast<bf16x4 *>(g_sink16);
-                *dst = outv;
-            }
-        }
-    }
-
-    constexpr size_t pstride = (size_t)9 * C * C + C;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int co = g4 * 4 + rr;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int tap = wv + 4 * n;
-            if (tap >= NTT) continue;
-            float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * C + co) * C + i16;
-            *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
-        }
-        if (wv == 0 && i16 == 0) {
-            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * C * C + co;
-            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
-        }
-    }
-}
-
-// ... and for the first convolution of encoder block 1 (8 -> 16 forward): its data gradient (16 -> 8) takes the stored
-// activation x = t[0] as ReLU source AND accumulates into the skip gradient the decoder left in dx, its weight gradient
-// reads the same x and the same g: conv3x3_wgrad_kernel<8, 16, false> + conv3x3_ring_kernel<16, 16, 2, true, false, true>.
-__global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const Bwd8Args a)
-{
-    constexpr int PX = 8, PG = 16, NTW = 2, NTT = 5, NS = 5, NT = 4;
-    __shared__ __attribute__((aligned(16))) bf16 x_tile[(HT * WT + 8) * PX];
-    __shared__ __attribute__((aligned(16))) bf16 g_tile[(HT * WT + 8) * PG];
-    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int tpi = tiles_x * tiles_y;
-    const int total_tiles = tpi * a.B;
-    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-
-    // ---- weight-gradient side (x: 8 channels, g: 16 channels)
-    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-    unsigned b_ad[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        const int nt = wv + 4 * n;
-        int tap = 2 * nt + (pp >> 1);
-        const int col = 4 * (pp & 1);
-        tap = tap > 8 ? 8 : tap;
-        const int ty = tap / 3, tx = tap % 3;
-        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PX + col) * 2);
-    }
-    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PG + 4 * pp) * 2);
-
-    // ---- data-gradient side (input g: 16 channels, output: 8 channels)
-    int d_lane[NS];
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-        int tap = 2 * ks + (lane >> 5);
-        const int ch = 8 * ((lane >> 4) & 1);
-        tap = tap > 8 ? 8 : tap;
-        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PG + ch;
-    }
-    const int n8 = lane >> 4;
-    const int lrow8 = 2 * wv + (n8 >> 1), lcol8 = (n8 & 1) * 16 + (lane & 15);
-    const int lpix8 = lrow8 * a.W + lcol8;
-    const int s_off8 = ((lrow8 + 1) * WT + lcol8 + 1) * PX;
-    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
-
-    constexpr int NX = HT * WT, NG = HT * WT * 2;
+    // register prefetch of the next tile's operands while the current one is consumed; every load is unconditional
+    constexpr int NX = HT * WT * GX, NG = HT * WT * GG;
     constexpr int RX = (NX + CONV_THREADS - 1) / CONV_THREADS, RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
     u32x4 rx[RX], rg[RG];
     auto load_tile = [&](int t) {
@@ -2007,21 +1628,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
         for (int i = 0; i < RX; ++i) {
             int gi = tv + i * CONV_THREADS;
             gi = gi < NX ? gi : NX - 1;
-            const int dy = gi / WT - 1, dx = gi % WT - 1;
+            const int pix = gi / GX, half = gi % GX;
+            const int dy = pix / WT - 1, dx = pix % WT - 1;
             const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.x + (long)(pix0 + dy * a.W + dx) * 8) : &g_zero16);
+            const long po = pix0 + dy * a.W + dx;
+            const bf16 *src = split ? (half ? a.x2 : a.x) + po * 8 : a.x + po * CX + half * 8;
+            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16);
         }
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
             int gi = tv + i * CONV_THREADS;
             gi = gi < NG ? gi : NG - 1;
-            const int pix = gi >> 1, gc = gi & 1;
+            const int pix = gi / GG, gc = gi % GG;
             const int dy = pix / WT - 1, dx = pix % WT - 1;
             const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + (long)(pix0 + dy * a.W + dx) * 16 + gc * 8) : &g_zero16);
+            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + (long)(pix0 + dy * a.W + dx) * CG + gc * 8) : &g_zero16);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&]() {          // (pitch = channel count: granule gi of a tile sits at element 8 gi)
         int tv = tid;
         asm volatile("" : "+v"(tv));
 #pragma unroll
@@ -2036,6 +1660,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
         }
     };
 
+    // XCD-contiguous persistent tile walk, as in conv3x3_wgrad_kernel (one partial slice per block)
     int t_first, t_step, t_end;
     if ((gridDim.x & 7) == 0) {
         const int per_xcd = (total_tiles + 7) / 8;
@@ -2057,41 +1682,45 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
         store_tile();
         __syncthreads();
         // the accumulate target of this tile's epilogue, ahead of the next tile's operands in the load queue
-        const u32x4 e8_acc = *(ok8 ? reinterpret_cast<const u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : &g_zero16);
+        u32x4 e8_acc = {0u, 0u, 0u, 0u};
+        if constexpr (CX == 8) e8_acc = *((ok8 && a.accumulate_dx) ? reinterpret_cast<const u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : &g_zero16);
         {
             const int nt = t + t_step;
             load_tile(nt < t_end ? nt : t);
         }
+        // ---- weight gradient: tile rows 0..7, the fragments of row r+1 in flight while row r is consumed
         i32x2 fa[2][2], fb[2][2 * NTW];
-#define BX_ISSUE(R, BUF)                                                                     \
+#define BF_ISSUE(R, BUF)                                                                     \
     {                                                                                        \
-        fa[BUF][0] = tr_read_o<((R) * WT * PG) * 2>(g_ad);                                   \
-        fa[BUF][1] = tr_read_o<((R) * WT * PG + 16 * PG) * 2>(g_ad);                         \
+        fa[BUF][0] = tr_read_o<((R) * WT * CG) * 2>(g_ad);                                   \
+        fa[BUF][1] = tr_read_o<((R) * WT * CG + 16 * CG) * 2>(g_ad);                         \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
-            fb[BUF][2 * n] = tr_read_o<((R) * WT * PX) * 2>(b_ad[n]);                        \
-            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PX + 16 * PX) * 2>(b_ad[n]);          \
+            fb[BUF][2 * n] = tr_read_o<((R) * WT * CX) * 2>(b_ad[n]);                        \
+            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * CX + 16 * CX) * 2>(b_ad[n]);          \
         }                                                                                    \
     }
-#define BX_CONSUME(BUF)                                                                      \
+#define BF_CONSUME(BUF)                                                                      \
     {                                                                                        \
         const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
         accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
     }
-#define BX_STEP(R)                                                                           \
+#define BF_STEP(R)                                                                           \
     {                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
         __builtin_amdgcn_sched_barrier(0);                                                   \
-        if ((R) + 1 < TH) BX_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
+        if ((R) + 1 < TH) BF_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
         __builtin_amdgcn_sched_barrier(0);                                                   \
-        BX_CONSUME((R) & 1);                                                                 \
+        BF_CONSUME((R) & 1);                                                                 \
     }
-        BX_ISSUE(0, 0);
-        BX_STEP(0) BX_STEP(1) BX_STEP(2) BX_STEP(3) BX_STEP(4) BX_STEP(5) BX_STEP(6) BX_STEP(7)
-#undef BX_STEP
-#undef BX_CONSUME
-#undef BX_ISSUE
+        BF_ISSUE(0, 0);
+        BF_STEP(0) BF_STEP(1) BF_STEP(2) BF_STEP(3) BF_STEP(4) BF_STEP(5) BF_STEP(6) BF_STEP(7)
+        static_assert(TH == 8, "BF_STEP expansion above covers 8 tile rows");
+#undef BF_STEP
+#undef BF_CONSUME
+#undef BF_ISSUE
+        // ---- data gradient of the tile
         f32x4 dacc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2100,17 +1729,27 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
             const bf16 *bl = g_tile + d_lane[ks];
             bf16x8 bf[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PG);
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * CG);
             const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
 #pragma unroll
             for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
         }
-        const u32x4 e8_src = *reinterpret_cast<const u32x4 *>(x_tile + s_off8);
+        u32x4 e8_src = {0u, 0u, 0u, 0u};
+        bf16x4 e_src[NT];
+        if constexpr (CX == 8) {
+            e8_src = *reinterpret_cast<const u32x4 *>(x_tile + s_off8);
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) e_src[n] = *reinterpret_cast<const bf16x4 *>(x_tile + s_off[n]);
+        }
+        // the next tile's operands have had the MFMA work to arrive: take delivery in front of this tile's stores (loads and
+        // stores share vmcnt and complete out of order: a wait for them behind the stores is a wait for the stores to drain)
 #pragma unroll
         for (int i = 0; i < RX; ++i) asm volatile("" : "+v"(rx[i]));
 #pragma unroll
         for (int i = 0; i < RG; ++i) asm volatile("" : "+v"(rg[i]));
-        {
+        // (the additions of zero below are the ring kernel's bias and accumulate-target additions: they turn -0 into +0)
+        if constexpr (CX == 8) {
             float v8[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -2126,211 +1765,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv8x16_bwd_fused_kernel(const 
             unpack8(e8_acc, av);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float v = fmaxf(v8[r] + 0.f, -INFINITY);                   // (the ring kernel's bias addition)
+                const float v = fmaxf(v8[r] + 0.f, -INFINITY);
                 const float masked = (sv[r] > 0.f) ? v * a.scale : 0.f;
                 v8[r] = masked + av[r];
             }
             u32x4 *dst8 = ok8 ? reinterpret_cast<u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : reinterpret_cast<u32x4 *>(g_sink16);
             *dst8 = pack8(v8);
-        }
-    }
-
-    // ---- flush (conv3x3_wgrad_kernel<8, 16, false> with COUT = 16, CIN = 8)
-    constexpr size_t pstride = (size_t)9 * 16 * 8 + 16;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int co = g4 * 4 + rr;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int nt = wv + 4 * n;
-            if (nt >= NTT) continue;
-            const int tap = 2 * nt + (i16 >> 3), ci = i16 & 7;
-            if (tap < 9) {
-                float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 16 + co) * 8 + ci;
-                *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
-            }
-        }
-        if (wv == 0 && i16 == 0) {
-            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 16 * 8 + co;
-            *d = a.acc_partials ? *d + accb[rr] : accb[rr];
-        }
-    }
-}
-
-// ... and for the second application of the last decoder block's first convolution (16 -> 8 forward on concat(skip, d1)):
-// its data gradient (8 -> 16) produces the skip's and d1's gradients, each masked by its own stored activation -- the two
-// halves of the weight gradient's input: conv3x3_wgrad_kernel<16, 16, true> + conv3x3_ring_kernel<8, 16, 2, true, false, false>.
-__global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const Bwd8Args a)
-{
-    constexpr int PX = 16, PG = 8, NTW = 3, NTT = 9, NS = 3, NT = 4;
-    __shared__ __attribute__((aligned(16))) bf16 x_tile[(HT * WT + 8) * PX];
-    __shared__ __attribute__((aligned(16))) bf16 g_tile[(HT * WT + 8) * PG];
-    __shared__ __attribute__((aligned(16))) bf16 w_lds[NS * 64 * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int tpi = tiles_x * tiles_y;
-    const int total_tiles = tpi * a.B;
-    const int i16 = lane & 15, g4 = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-
-    f32x4 acc[NTW], accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-    unsigned b_ad[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        int tap = wv + 4 * n;
-        tap = tap > 8 ? 8 : tap;
-        const int ty = tap / 3, tx = tap % 3;
-        b_ad[n] = lds_addr(x_tile) + (unsigned)((((ty * WT) + 4 * g4 + q + tx) * PX + 4 * pp) * 2);
-    }
-    const unsigned g_ad = lds_addr(g_tile) + (unsigned)(((WT + 1 + 4 * g4 + q) * PG + 4 * pp) * 2);
-
-    int d_lane[NS];
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-        int tap = 4 * ks + (lane >> 4);
-        tap = tap > 8 ? 8 : tap;
-        d_lane[ks] = ((2 * wv + tap / 3) * WT + (lane & 15) + tap % 3) * PG;
-    }
-    int o_pix[NT], s_off[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int r = 2 * wv + (n >> 1), c = (n & 1) * 16 + (lane & 15);
-        o_pix[n] = r * a.W + c;
-        s_off[n] = ((r + 1) * WT + c + 1) * PX + (lane >> 4) * 4;
-    }
-    // two 8-channel halves (x | x2 in, dx | dx2 out, each output half masked by its input half), or -- x2 = dx2 = null -- one
-    // 16-channel input and one unmasked 16-channel output (a data gradient without ReLU source: the first application of
-    // the decoder convolution, whose input is the up-sampled tensor)
-    const bool split = a.x2 != nullptr;
-    bf16 *const o_base = split ? ((lane >> 5) ? a.dx2 : a.dx) + ((lane >> 4) & 1) * 4 : a.dx + (lane >> 4) * 4;
-    const int o_stride = split ? 8 : 16;
-    for (int i = tid; i < NS * 64; i += CONV_THREADS) reinterpret_cast<u32x4 *>(w_lds)[i] = reinterpret_cast<const u32x4 *>(a.wpack_t)[i];
-
-    constexpr int NX = HT * WT * 2, NG = HT * WT;
-    constexpr int RX = (NX + CONV_THREADS - 1) / CONV_THREADS, RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
-    u32x4 rx[RX], rg[RG];
-    auto load_tile = [&](int t) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-        const int pix0 = (b * a.H + ty0) * a.W + tx0;
-#pragma unroll
-        for (int i = 0; i < RX; ++i) {
-            int gi = tv + i * CONV_THREADS;
-            gi = gi < NX ? gi : NX - 1;
-            const int pix = gi >> 1, half = gi & 1;
-            const int dy = pix / WT - 1, dx = pix % WT - 1;
-            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            const long po = pix0 + dy * a.W + dx;
-            const bf16 *src = split ? (half ? a.x2 : a.x) + po * 8 : a.x + po * 16 + half * 8;
-            rx[i] = *(ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16);
-        }
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-            int gi = tv + i * CONV_THREADS;
-            gi = gi < NG ? gi : NG - 1;
-            const int dy = gi / WT - 1, dx = gi % WT - 1;
-            const bool ok = (unsigned)(ty0 + dy) < (unsigned)a.H && (unsigned)(tx0 + dx) < (unsigned)a.W;
-            rg[i] = *(ok ? reinterpret_cast<const u32x4 *>(a.g + (long)(pix0 + dy * a.W + dx) * 8) : &g_zero16);
-        }
-    };
-    auto store_tile = [&]() {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int i = 0; i < RX; ++i) {
-            const int gi = tv + i * CONV_THREADS;
-            if (gi < NX) *reinterpret_cast<u32x4 *>(x_tile + (size_t)gi * 8) = rx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-            const int gi = tv + i * CONV_THREADS;
-            if (gi < NG) *reinterpret_cast<u32x4 *>(g_tile + (size_t)gi * 8) = rg[i];
-        }
-    };
-
-    int t_first, t_step, t_end;
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (total_tiles + 7) / 8;
-        const int xcd = blockIdx.x & 7;
-        t_first = xcd * per_xcd + ((int)blockIdx.x >> 3);
-        t_step = (int)gridDim.x >> 3;
-        t_end = min(total_tiles, (xcd + 1) * per_xcd);
-    } else {
-        t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
-    }
-    if (t_first < t_end) load_tile(t_first);
-    for (int t = t_first; t < t_end; t += t_step) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);
-        }
-        i32x2 fa[2][2], fb[2][2 * NTW];
-#define BY_ISSUE(R, BUF)                                                                     \
-    {                                                                                        \
-        fa[BUF][0] = tr_read_o<((R) * WT * PG) * 2>(g_ad);                                   \
-        fa[BUF][1] = tr_read_o<((R) * WT * PG + 16 * PG) * 2>(g_ad);                         \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                    \
-            fb[BUF][2 * n] = tr_read_o<((R) * WT * PX) * 2>(b_ad[n]);                        \
-            fb[BUF][2 * n + 1] = tr_read_o<((R) * WT * PX + 16 * PX) * 2>(b_ad[n]);          \
-        }                                                                                    \
-    }
-#define BY_CONSUME(BUF)                                                                      \
-    {                                                                                        \
-        const bf16x8 af = frag_from(fa[BUF][0], fa[BUF][1]);                                 \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                      \
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_from(fb[BUF][2 * n], fb[BUF][2 * n + 1]), acc[n], 0, 0, 0); \
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb, 0, 0, 0);             \
-    }
-#define BY_STEP(R)                                                                           \
-    {                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        if ((R) + 1 < TH) BY_ISSUE(((R) + 1 < TH ? (R) + 1 : 0), ((R) + 1) & 1);             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        BY_CONSUME((R) & 1);                                                                 \
-    }
-        BY_ISSUE(0, 0);
-        BY_STEP(0) BY_STEP(1) BY_STEP(2) BY_STEP(3) BY_STEP(4) BY_STEP(5) BY_STEP(6) BY_STEP(7)
-#undef BY_STEP
-#undef BY_CONSUME
-#undef BY_ISSUE
-        f32x4 dacc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) dacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-            const bf16 *bl = g_tile + d_lane[ks];
-            bf16x8 bf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8 *>(bl + ((n >> 1) * WT + (n & 1) * 16) * PG);
-            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(w_lds + ((size_t)(ks * 64 + lane)) * 8);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) dacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], dacc[n], 0, 0, 0);
-        }
-        bf16x4 e_src[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) e_src[n] = *reinterpret_cast<const bf16x4 *>(x_tile + s_off[n]);
-#pragma unroll
-        for (int i = 0; i < RX; ++i) asm volatile("" : "+v"(rx[i]));
-#pragma unroll
-        for (int i = 0; i < RG; ++i) asm volatile("" : "+v"(rg[i]));
-        {
-            const int b = t / tpi, tr = t - b * tpi;
-            const int tyi = tr / tiles_x;
-            const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
-            const int pix0 = (b * a.H + ty0) * a.W + tx0;
+        } else {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const bool okp = (ty0 + 2 * wv + (n >> 1)) < a.H && (tx0 + (n & 1) * 16 + (lane & 15)) < a.W;
@@ -2339,7 +1780,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(dacc[n][r] + 0.f, -INFINITY);
                     const float masked = ((float)e_src[n][r] > 0.f) ? v * a.scale : 0.f;
-                    outv[r] = (bf16)(split ? masked + 0.f : v);
+                    outv[r] = (bf16)(a.masked ? masked + 0.f : v);
                 }
                 bf16x4 *dst = okp ? reinterpret_cast<bf16x4 *>(o_base + (long)(pix0 + o_pix[n]) * o_stride) : reinterpret_cast<bf16x4 *>(g_sink16);
                 *dst = outv;
@@ -2347,21 +1788,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv16x8_bwd_fused_kernel(const 
         }
     }
 
-    // ---- flush (conv3x3_wgrad_kernel<16, 16, true> with COUT = 8, CIN = 16)
-    constexpr size_t pstride = (size_t)9 * 8 * 16 + 8;
+    // ---- flush the block's partial slice: [tap][co < CG][ci < CX] weight sums, then CG bias sums
+    constexpr size_t pstride = (size_t)9 * CG * CX + CG;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int co = g4 * 4 + rr;
-        if (co >= 8) continue;
+        if (co >= CG) continue;
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            const int tap = wv + 4 * n;
-            if (tap >= NTT) continue;
-            float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * 8 + co) * 16 + i16;
-            *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+            const int nt = wv + 4 * n;
+            if (nt >= NTT) continue;
+            const int tap = CX == 8 ? 2 * nt + (i16 >> 3) : nt;
+            const int ci = CX == 8 ? (i16 & 7) : i16;
+            if (tap < 9) {
+                float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * CG + co) * CX + ci;
+                *d = a.acc_partials ? *d + acc[n][rr] : acc[n][rr];
+            }
         }
         if (wv == 0 && i16 == 0) {
-            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * 8 * 16 + co;
+            float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * CG * CX + co;
             *d = a.acc_partials ? *d + accb[rr] : accb[rr];
         }
     }
@@ -3786,21 +3231,29 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
     return MMK_OK;
 }
 
+template <int CX, int CG>
+int launch_bwd_fused(const BwdFusedArgs &a, int c1, hipStream_t st)
+{
+    const int spatial = wgrad_slices(CG, CX, c1, a.B, a.H, a.W);     // the partial slices of the two-kernel path: same layout, same sums
+    if (spatial < 1) {
+        mmk::set_error("fused backward: occupancy query failed");
+        return MMK_ERR_HIP;
+    }
+    hipLaunchKernelGGL((conv_bwd_fused_kernel<CX, CG>), dim3(spatial), dim3(CONV_THREADS), 0, st, a);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
 extern "C" int mmk_conv_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
                                   int32_t C, void *dx, float *partials, int32_t accumulate, void *stream)
 {
     MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv_bwd_fused: NULL pointer");
     MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2 && (C == 8 || C == 16), "mmk_conv_bwd_fused: bad shape (8 or 16 channels)");
     MMK_REQUIRE((size_t)B * H * W * C < ((size_t)1 << 31), "mmk_conv_bwd_fused: tensor too large for 32-bit offsets");
-    const int spatial = wgrad_slices(C, C, C, B, H, W);        // the partial slices of the two-kernel path: same layout, same sums
-    MMK_REQUIRE(spatial >= 1, "mmk_conv_bwd_fused: occupancy query failed");
-    Bwd8Args a;
-    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
+    BwdFusedArgs a = {};
+    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale; a.masked = 1;
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
-    if (C == 8) hipLaunchKernelGGL(conv8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
-    MMK_LAUNCH_CHECK();
-    return MMK_OK;
+    return C == 8 ? launch_bwd_fused<8, 8>(a, 8, (hipStream_t)stream) : launch_bwd_fused<16, 16>(a, 16, (hipStream_t)stream);
 }
 
 extern "C" int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *wpack_t, float scale, int32_t B, int32_t H, int32_t W,
@@ -3809,14 +3262,11 @@ extern "C" int mmk_conv8x16_bwd_fused(const void *x, const void *g, const void *
     MMK_REQUIRE(x && g && wpack_t && dx && partials, "mmk_conv8x16_bwd_fused: NULL pointer");
     MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv8x16_bwd_fused: bad shape");
     MMK_REQUIRE((size_t)B * H * W * 16 < ((size_t)1 << 31), "mmk_conv8x16_bwd_fused: tensor too large for 32-bit offsets");
-    const int spatial = wgrad_slices(16, 8, 8, B, H, W);
-    MMK_REQUIRE(spatial >= 1, "mmk_conv8x16_bwd_fused: occupancy query failed");
-    Bwd8Args a;
-    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale;
+    BwdFusedArgs a = {};
+    a.x = (const bf16 *)x; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t; a.dx = (bf16 *)dx; a.scale = scale; a.masked = 1;
+    a.accumulate_dx = 1;
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
-    hipLaunchKernelGGL(conv8x16_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
-    MMK_LAUNCH_CHECK();
-    return MMK_OK;
+    return launch_bwd_fused<8, 16>(a, 8, (hipStream_t)stream);
 }
 
 extern "C" int mmk_conv16x8_bwd_fused(const void *x1, const void *x2, const void *g, const void *wpack_t, float scale, int32_t B,
@@ -3826,15 +3276,11 @@ extern "C" int mmk_conv16x8_bwd_fused(const void *x1, const void *x2, const void
     MMK_REQUIRE((x2 == nullptr) == (dx2 == nullptr), "mmk_conv16x8_bwd_fused: x2 and dx2 go together (both NULL: one 16-channel input / unmasked output)");
     MMK_REQUIRE(B >= 1 && H >= 2 && W >= 2, "mmk_conv16x8_bwd_fused: bad shape");
     MMK_REQUIRE((size_t)B * H * W * 16 < ((size_t)1 << 31), "mmk_conv16x8_bwd_fused: tensor too large for 32-bit offsets");
-    const int spatial = wgrad_slices(8, 16, 8, B, H, W);
-    MMK_REQUIRE(spatial >= 1, "mmk_conv16x8_bwd_fused: occupancy query failed");
-    Bwd8Args a;
+    BwdFusedArgs a = {};
     a.x = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.g = (const bf16 *)g; a.wpack_t = (const bf16 *)wpack_t;
-    a.dx = (bf16 *)dx1; a.dx2 = (bf16 *)dx2; a.scale = scale;
+    a.dx = (bf16 *)dx1; a.dx2 = (bf16 *)dx2; a.scale = scale; a.masked = x2 != nullptr;
     a.B = B; a.H = H; a.W = W; a.partials = partials; a.acc_partials = accumulate;
-    hipLaunchKernelGGL(conv16x8_bwd_fused_kernel, dim3(spatial), dim3(CONV_THREADS), 0, (hipStream_t)stream, a);
-    MMK_LAUNCH_CHECK();
-    return MMK_OK;
+    return launch_bwd_fused<16, 8>(a, x2 ? 8 : 16, (hipStream_t)stream);
 }
 
 extern "C" int32_t mmk_conv3x3_wgrad_slices(int32_t cout, int32_t cin, int32_t c1, int32_t B, int32_t H, int32_t W)

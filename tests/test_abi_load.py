@@ -27,7 +27,8 @@ def test_header_symbols_exported(L):
     for n in sorted(names):
         assert hasattr(L, n), "symbol %s declared in mmk.h is not exported" % n
     assert names == set(_lib.EXPORTED.keys()), names ^ set(_lib.EXPORTED.keys())
-    assert L.mmk_version() == 210
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mmk.h")).read()
+    assert L.mmk_version() == int(re.search(r"#define\s+MMK_VERSION\s+(\d+)", hdr).group(1))
 
 
 def test_host_side_argument_checks(L):
