@@ -538,6 +538,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         }
         gz = at(sc, p.gz_up[j].off);
     }
+    // the decoder's weight gradients are all enqueued: their slices are reduced under the >= 64-channel encoder levels, which
+    // leave the HBM idle
+    static const bool split3 = !(getenv("MMK_UNPACK_SPLIT") && getenv("MMK_UNPACK_SPLIT")[0] == '0');
+    if (split3) MMK_TRY(unpack(12, 21));
     // ---- encoder, i = 5..1 (g_t = gradient w.r.t. t[i])
     const void *g_t = gz;
     for (int i = 5; i >= 1; --i) {
@@ -569,10 +573,11 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             MMK_TRY(conv(p, h, w, sl, c2, stream));
         }
         g_t = tgt;
-        // every layer but the three at 640 x 640 has its weight gradients enqueued: reduce them now, under the rest of the chain
-        // (the reduction reads all partial slices -- most of them belong to the >= 64-channel layers -- and would otherwise
-        // be the tail of the backward pass)
-        if (i == 2) MMK_TRY(unpack(4, 21));
+        // the >= 64-channel encoder layers have their weight gradients enqueued: reduce their slices now (the reduction reads
+        // every partial slice; as one launch at the end it is the tail of the backward pass, and beside the 640 x 640 kernels
+        // it competes for their HBM bandwidth)
+        if (i == 3 && split3) MMK_TRY(unpack(6, 11));
+        if (i == 2 && !split3) MMK_TRY(unpack(4, 21));
     }
     // ---- encoder block 0
     if (can_fuse(1, 8, p.H, p.W)) {
@@ -584,9 +589,9 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         c.src1 = at(ws, p.a_enc[0].off); c.scale1 = 1.f;
         MMK_TRY(conv(p, p.H, p.W, sl, c, stream));
     }
-    // ---- parameter gradients of the first three 3x3 layers (the rest was reduced while the 640 x 640 levels were still
-    // running): on the weight-gradient stream, beside the first layer's weight gradient
-    MMK_TRY(unpack(1, 3));
+    // ---- parameter gradients of the first five 3x3 layers (the rest was reduced on the way): on the weight-gradient stream,
+    // beside the first layer's weight gradient
+    MMK_TRY(unpack(1, split3 ? 5 : 3));
     MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1], stream));
     if (ss) {       // join: the caller's stream continues only after every gradient is written
         MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
