@@ -139,6 +139,35 @@ def test_icp_forward_matches_oracle(icp_type, loss, dim):
         assert err < 0.5 * err0
 
 
+def test_icp_zero_rows_anywhere_match_oracle():
+    """The scan visits identical all-zero rows once (mmk_icp.hip: src_zero_scan_kernel / src_units_kernel).  Zero rows need
+    not be trailing padding: a whole 512-row block of zeros in the middle of a scan, zero rows at the front, a scan of
+    nothing but zeros and one without any -- correspondences of every row and every iteration equal the oracle's."""
+    B, n, m, dim = 4, 2048, 3000, 2
+    src, tgt, _ = _pair_batch(B, n, m, dim, pad_n=0, pad_m=40, seed=91)
+    src[0, 512:1024] = 0.0                 # a zero block in the middle, real rows behind it
+    src[0, 100:110] = 0.0                  # ... and the first zero row in an earlier, mixed block
+    src[1, :600] = 0.0                     # zeros at the front (the first block is all zero and holds the representative)
+    src[2] = 0.0                           # nothing but zeros
+    rng = np.random.default_rng(4)
+    w = rng.uniform(0.1, 1.0, (B, n)).astype(np.float32)
+    K = 6
+    loss_fn = {"name": "huber", "metric": 1.0}
+    ref = dicp_ref.ICPRef("pt2pl", differentiable=False, max_iterations=K, tolerance=1e-9)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.eye(4).repeat(B, 1, 1),
+                  weight=torch.from_numpy(w), trim_dist=5.0, loss_fn=loss_fn, dim=dim)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-9)
+    wt = torch.from_numpy(w).to(DEV).requires_grad_(True)
+    T = icp.icp(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), T_init=torch.eye(4, device=DEV).repeat(B, 1, 1),
+                weight=wt, trim_dist=5.0, loss_fn=loss_fn, dim=dim)["T"]
+    saved = T.grad_fn.saved_tensors
+    idx_hist, T_hist = saved[3].cpu().numpy(), saved[4].cpu().numpy().reshape(K + 1, B, 4, 4)
+    for k in range(out["num_iter"]):
+        act = out["hist"]["active"][k].numpy()
+        np.testing.assert_array_equal(idx_hist[k][act], out["hist"]["idx"][k].numpy()[act], err_msg="iteration %d" % k)
+        np.testing.assert_allclose(T_hist[k + 1], out["hist"]["T"][k + 1].numpy(), atol=2e-6)
+
+
 @pytest.mark.parametrize("icp_type,loss,dim", CASES[:4])
 def test_icp_backward_matches_autograd(icp_type, loss, dim):
     B, n, m = 2, 900, 2500
