@@ -1491,7 +1491,10 @@ int wgrad_spatial(int cout, int cin, int B, int H, int W)
         int nblk = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, conv3x3_wgrad_kernel<CK, CM, G8>, CONV_THREADS, smem) != hipSuccess)
             return -1;
-        per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
+        // (the 8/16-channel shapes share their slices -- one per block -- with the fused backward kernels, which hold 4 blocks
+        // per CU: with 6-8 slices per CU those run a second, half-empty round of blocks, 3-8 % slower)
+        const int cap = (CK <= 16 && CM == 16) ? 4 : 8;
+        per_cu[dev & 63] = nblk < 1 ? 1 : (nblk > cap ? cap : nblk);
     }
     const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int chunks = cin / CK, groups = (cout + CM - 1) / CM;
