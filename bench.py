@@ -182,6 +182,83 @@ def grid_engine_block(model, one_step, first, B, L, steps=5):
         model.ICP_alg.nn_search, model.ICP_alg_inference.nn_search = engines
 
 
+def timed_steps(fn, n, device):
+    """HIP-event time of n calls of fn on the current stream, after one untimed call (ms per call)."""
+    fn(0)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        fn(1 + i)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) / n
+
+
+def valid_scan_points(batch):
+    """Non-padding rows of the scan clouds (the reference pads with all-zero rows: icp_weight_dataset.py:379-381)."""
+    return (batch["loc_data"]["filtered_pc"] != 0).any(dim=-1).sum(dim=1).float()
+
+
+def side_blocks(model, opt, lw, params, device, B, steps=5):
+    """Side measurements on rank 0 at N=1 (never `value`):
+      sparse_scene  the same step on the scenes of rounds 1-2 (2 450-2 970 valid scan points per pair)
+      dim3          the same step with the SE(3) / 6x6 solve (params["icp_dim"] = 3, 3-D map; SURVEY.md §8d config 3 variant)
+      inference     validate_policy-style forward (model.eval(), no_grad, ICP_alg_inference: 50 iterations, early exit;
+                    train_icp_weights.py:71-177) at B = 16 (configs[1]) and B = 32, in pairs/s"""
+    from mm_masking_amd import synthetic
+    from mm_masking_amd import train_icp_weights as trn
+    out = {}
+    raws = [synthetic.make_batch(list(range(5000 + i * B, 5000 + (i + 1) * B)), device=device, m_valid=M_VALID, m_pad=M_PAD,
+                                 density="sparse") for i in range(2)]
+
+    def step_on(rs, prm):
+        def f(i):
+            trn.train_step(model, trn.prepare_batch(rs[i % len(rs)], prm, max_loc_pts=N_PAD), opt, lw, device)
+        return f
+    ms = timed_steps(step_on(raws, params), steps, device)
+    out["sparse_scene"] = {"ms_per_step": ms, "pairs_per_s": B / ms * 1e3,
+                           "scan_pts_valid_mean": float(valid_scan_points(trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD)).mean()),
+                           "note": "labelled side line: the round-1/2 scene density (synthetic.DENSITY['sparse'])"}
+    del raws
+    raws3 = [synthetic.make_batch(list(range(6000 + i * B, 6000 + (i + 1) * B)), device=device, m_valid=M_VALID, m_pad=M_PAD, dim=3)
+             for i in range(2)]
+    dim_was = model.icp_dim
+    model.icp_dim = 3
+    try:
+        ms3 = timed_steps(step_on(raws3, params), steps, device)
+    finally:
+        model.icp_dim = dim_was
+    out["dim3"] = {"ms_per_step": ms3, "pairs_per_s": B / ms3 * 1e3,
+                   "note": "same step with icp_dim=3: SE(3) pose, 6x6 Gauss-Newton, 3-D nearest neighbour on a map with heights and "
+                           "tilted normals (synthetic.make_pair(dim=3))"}
+    del raws3
+    model.eval()
+    try:
+        inf = {}
+        for b in (16, 32):
+            rawi = [synthetic.make_batch(list(range(7000 + i * b, 7000 + (i + 1) * b)), device=device, m_valid=M_VALID, m_pad=M_PAD,
+                                         dataset_type="val") for i in range(2)]
+            its = []
+
+            def f(i):
+                batch = trn.prepare_batch(rawi[i % 2], params, max_loc_pts=N_PAD)
+                with torch.no_grad():
+                    T, _, _ = model(batch["loc_data"], batch["map_data"], batch["transforms"]["T_ml_init"])
+                    trn.eval_validation_loss(T, batch["transforms"]["T_ml_gt"])
+                its.append(model.ICP_alg_inference.last_iterations)
+            msi = timed_steps(f, steps, device)
+            inf["B%d" % b] = {"ms_per_batch": msi, "pairs_per_s": b / msi * 1e3,
+                              "icp_iterations_run": [int(v) for v in its[1:] if v is not None]}
+        inf["note"] = ("validate_policy path: prepare_batch + U-Net forward + extract_weights + ICP_alg_inference (differentiable=False, "
+                       "max 50 iterations, tolerance 1e-5, early exit polled every 8 iterations) + eval_validation_loss; "
+                       "T_init ~ N(0, 2 m / 0.6 rad) as the reference's validation split")
+        out["inference"] = inf
+    finally:
+        model.train()
+    return out
+
+
 def pose_parity(model, params, device, pairs=2):
     """Part of the cpu_baseline leg: GPU dICP vs the CPU restatement on identical inputs
     (the oracle as checker, outside the timed region)."""
@@ -227,6 +304,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the side measurement of the exact grid NN engine")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (sparse scenes, dim 3, inference)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -387,12 +465,22 @@ def main():
             skipped = blk_zero & (first_zero.view(-1, 1) < starts)
             scanned = float((N_PAD - 512 * skipped.sum(dim=1)).float().mean().item())
         evals = active_pairs * scanned * M_PAD       # distance evaluations per launch
-        # HBM bytes per launch from the PMC counters: measured in a separate rocprofv3 --pmc pass of this same
-        # command (scripts/prof_nn.py -> profiles/r02_nn_traffic.json, committed); null when that file is absent
-        traffic = None
-        tr_file = os.path.join(ROOT, "profiles", "r02_nn_traffic.json")
-        if os.path.exists(tr_file) and model.ICP_alg.nn_search == "brute":
-            traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
+        # HBM bytes per launch from the PMC counters: NOT measured in this run -- read from a committed file that a separate
+        # rocprofv3 --pmc pass over the dICP alone wrote (scripts/pmc_nn.sh -> profiles/r03_nn_traffic.json, FETCH_SIZE and
+        # WRITE_SIZE in passes of their own, FETCH_SIZE doubled per the gfx950 correction); null when no such file exists.
+        # `traffic_source` says so in the line itself.
+        traffic, traffic_source = None, None
+        for name in ("r03_nn_traffic.json", "r02_nn_traffic.json"):
+            tr_file = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tr_file) and model.ICP_alg.nn_search == "brute":
+                tj = json.load(open(tr_file))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("committed PMC pass profiles/%s (dICP alone, %s us per launch there, scene density %s); not "
+                                  "collected in this run" % (name, tj.get("avg_launch_us", "?"), tj.get("density", "sparse (round 2)")))
+                break
+        valid = valid_scan_points(trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD))
+        # bytes a launch actually reads + writes: the scanned source rows (x,y), the target planes, one (idx, d2) per row
+        alg_bytes_read = active_pairs * (4 * DIM * scanned + 4 * DIM * M_PAD + 8 * N_PAD)
         result = {
             "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -406,13 +494,18 @@ def main():
                                     "400x3360 polar image, 3.3x the pixels; rot+trans loss), batch=%d per GPU" % B),
                        "batch_per_gpu": B, "global_batch": B * world, "scan_pts_pad": N_PAD, "map_pts": M_VALID,
                        "map_pts_pad": M_PAD, "icp_iters": ICP_ITERS, "parallelism": "dp%d" % world,
+                       "scene_density": "survey (SURVEY.md 8d: 3 500-5 000 valid scan points of 5 120)",
+                       "scan_pts_valid_mean": float(valid.mean()), "scan_pts_valid_min": float(valid.min()),
+                       "scan_pts_valid_max": float(valid.max()),
                        "final_loss": float(loss)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "grid_nn_kernel<2>" if model.ICP_alg.nn_search == "grid" else
                          ("nn_search_kernel<2, 16, 2>" if os.environ.get("MMK_NN_PREFILTER", "1") == "0" else "nn_prefilter_kernel<2, 2, 16>"),
                          "nn_engine": model.ICP_alg.nn_search, "launches_timed": int(len(nn_ms)),
                          "avg_launch_us": nn_avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_rows_read_per_launch": alg_bytes_read,
+                         "achieved_rows_read": alg_bytes_read / nn_avg_s / 1e9,
                          "active_pairs_per_launch": active_pairs, "source_rows_scanned_per_pair": scanned,
                          "note": "north_star names the HBM roofline; brute force does %.3g distance evaluations per "
                                  "launch over those bytes (~2.2 kFLOP/B), so the binding roofline is fp32 VALU" % evals,
@@ -428,6 +521,9 @@ def main():
             result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)
             if model.ICP_alg.nn_search == "brute" and not args.no_grid:
                 result["roofline_grid"] = grid_engine_block(model, one_step, args.warmup + args.steps, B, L)
+            if not args.no_side and not polar:
+                progress("side measurements: sparse scenes, dim 3, inference")
+                result.update(side_blocks(model, opt, lw, params, device, B))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(params)
             if not args.no_parity:

@@ -38,6 +38,17 @@ def weights_init(m):
             print("Skipping initialization of ", classname)
 
 
+def _global_extrema(c_min, c_max):
+    """min / max over the ranks of a data-parallel job (one MAX all-reduce of [-min, max]); the identity in a
+    single-process run.  Same reduction as unet_hip.channel_minmax(global_reduce=True) on the HIP path."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return c_min, c_max
+    t = torch.stack((-c_min.detach(), c_max.detach()))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return -t[0], t[1]
+
+
 class LearnICPWeightPolicy(nn.Module):
     def __init__(self, params):
         super().__init__()
@@ -85,9 +96,13 @@ class LearnICPWeightPolicy(nn.Module):
         self.unet_backend = params.get("unet_backend", "hip")
         if self.unet_backend not in ("hip", "torch"):
             raise ValueError("unet_backend must be 'hip' or 'torch' (got %r)" % (self.unet_backend,))
-        # data-parallel jobs: reduce the min-max normalisation's extrema over the ranks, so that it stays
-        # global over the whole batch as in the single-process reference (icp_weight_policy.py:151-155)
-        self.global_minmax = bool(params.get("global_minmax", False))
+        # data-parallel jobs: reduce the min-max normalisation's extrema over the ranks (one MAX all-reduce of 2C floats), so
+        # that it stays global over the whole batch as in the single-process reference (icp_weight_policy.py:151-155).
+        # Default: ON whenever the process is a rank of a multi-rank job, so that N ranks x B pairs normalise like one
+        # process over N*B pairs; params["global_minmax"] = False keeps it per rank.
+        import torch.distributed as dist
+        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.global_minmax = bool(params.get("global_minmax", multi_rank))
         self._step = 0
 
         self.mean_num_pts = 0.0
@@ -148,6 +163,8 @@ class LearnICPWeightPolicy(nn.Module):
             xc = input_data[:, c, :, :]
             if "minmax" in self.normalize_type:
                 c_max, c_min = torch.max(xc), torch.min(xc)
+                if self.global_minmax:
+                    c_min, c_max = _global_extrema(c_min, c_max)
                 xc = (xc - c_min) / (c_max - c_min)
             elif "standardize" in self.normalize_type:
                 xc = (xc - torch.mean(xc)) / torch.std(xc)

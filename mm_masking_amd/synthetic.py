@@ -19,6 +19,11 @@ import numpy as np
 import torch
 
 POLAR_RES = 0.0596
+# Scene density: "survey" = SURVEY.md §8d's workload (3 500-5 000 valid scan points of the 5 120 padded rows after
+# GO-CFAR + peak extraction: measured 3 798-4 893, mean 4 270 over pairs 0..63); "sparse" = the scenes of rounds 1-2
+# (2 450-2 970 valid points), kept for labelled side measurements.
+DENSITY = {"survey": {"walls": (240, 281), "hits": 13, "poles": (550, 701)},
+           "sparse": {"walls": (120, 181), "hits": 8, "poles": (250, 451)}}
 N_AZ = 400
 N_RANGE = 3360
 ENCODER = 5600
@@ -47,9 +52,9 @@ def se3_exp(xi):
     return T
 
 
-def _walls(rng, half=75.0):
+def _walls(rng, half=75.0, count=(240, 281)):
     segs = []
-    for _ in range(rng.integers(120, 181)):
+    for _ in range(rng.integers(*count)):
         c = rng.uniform(-half, half, 2)
         ang = rng.uniform(0, np.pi)
         L = rng.uniform(4.0, 30.0)
@@ -70,9 +75,9 @@ def _walls(rng, half=75.0):
     return segs[np.linalg.norm(mid, axis=1) > 6.0]
 
 
-def _poles(rng, half=75.0):
+def _poles(rng, half=75.0, count=(550, 701)):
     """Compact scatterers (poles, trunks): (K,2) positions, at least 6 m from the sensor."""
-    k = rng.integers(250, 451)
+    k = rng.integers(*count)
     r = rng.uniform(6.0, half, k)
     a = rng.uniform(0, 2 * np.pi, k)
     return np.stack([r * np.cos(a), r * np.sin(a)], axis=1)
@@ -106,7 +111,7 @@ def _lidar(rng, segs, poles, m_valid, m_pad, pad_val):
     return pc
 
 
-def _radar(rng, segs, poles, wobble=True):
+def _radar(rng, segs, poles, wobble=True, hits=13):
     counts = np.round(np.arange(N_AZ) * (ENCODER / N_AZ)).astype(np.int64)
     if wobble:
         counts = np.sort(np.clip(counts + rng.integers(-1, 2, N_AZ), 0, ENCODER - 1))
@@ -132,7 +137,7 @@ def _radar(rng, segs, poles, wobble=True):
 
     for a in range(N_AZ):
         amp = 1.0
-        for h in range(min(8, t.shape[1])):    # the beam partially penetrates: first eight walls
+        for h in range(min(hits, t.shape[1])):    # the beam partially penetrates: the first `hits` walls
             if not np.isfinite(t[a, h]):
                 break
             blob(a, t[a, h], rng.uniform(0.4, 0.9) * amp)
@@ -155,13 +160,23 @@ def _radar(rng, segs, poles, wobble=True):
 
 
 def make_pair(index, m_valid=20000, m_pad=20480, pad_val=1000.0, dataset_type="train", pos_std=2.0, rot_std=0.6,
-              wobble=True):
-    """One synthetic scan pair (numpy)."""
+              wobble=True, density="survey", dim=2):
+    """One synthetic scan pair (numpy).  ``dim=3`` (the SE(3) / 6x6 variant of SURVEY.md §8d config 3): the map points get
+    a height z ~ U(-1.5, 1.5) m and 40 % of the normals are tilted out of the plane -- drawn from a stream of their own,
+    so that everything else equals the dim-2 pair of the same index -- which makes z, roll and pitch observable for the
+    planar radar scan (z = 0) under the point-to-plane residual."""
     rng = np.random.default_rng(BASE_SEED + int(index))
-    segs = _walls(rng)
-    poles = _poles(rng)
+    dens = DENSITY[density]
+    segs = _walls(rng, count=dens["walls"])
+    poles = _poles(rng, count=dens["poles"])
     map_pc = _lidar(rng, segs, poles, m_valid, m_pad, pad_val)
-    fft, az, times = _radar(rng, segs, poles, wobble=wobble)
+    fft, az, times = _radar(rng, segs, poles, wobble=wobble, hits=dens["hits"])
+    if dim == 3:
+        r3 = np.random.default_rng([BASE_SEED + int(index), 3])
+        map_pc[:m_valid, 2] = r3.uniform(-1.5, 1.5, m_valid)
+        tilt = r3.uniform(-0.8, 0.8, m_valid) * (r3.uniform(0, 1, m_valid) < 0.4)
+        map_pc[:m_valid, 3:5] *= np.cos(tilt)[:, None].astype(np.float32)
+        map_pc[:m_valid, 5] = np.sin(tilt)
     if dataset_type == "train":
         xi = np.zeros(6)
         xi[0:2] = pos_std * rng.uniform(-1, 1, 2)

@@ -346,8 +346,8 @@ class SyntheticIterator:
     that ranks draw disjoint pairs of one seeded stream."""
 
     def __init__(self, params, batch_size, n_batches, rank=0, world_size=1, dataset_type="train", max_loc_pts=5120,
-                 m_valid=20000, m_pad=20480, start=0):
-        self.params, self.bs, self.nb = params, batch_size, n_batches
+                 m_valid=20000, m_pad=20480, start=0, density="survey"):
+        self.params, self.bs, self.nb, self.density = params, batch_size, n_batches, density
         self.rank, self.ws, self.kind = rank, world_size, dataset_type
         self.max_loc_pts, self.m_valid, self.m_pad, self.start = max_loc_pts, m_valid, m_pad, start
 
@@ -359,7 +359,7 @@ class SyntheticIterator:
         idx = [first + self.rank + j * self.ws for j in range(self.bs)]
         return synthetic.make_batch(idx, device=self.params["device"], m_valid=self.m_valid, m_pad=self.m_pad,
                                     dataset_type=self.kind, pos_std=self.params["pos_std"],
-                                    rot_std=self.params["rot_std"])
+                                    rot_std=self.params["rot_std"], density=self.density)
 
     def __iter__(self):
         for i in range(self.nb):

@@ -18,10 +18,10 @@ from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
 from oracle import train_ref, unet_ref
 
 
-def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
+def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None, dim=2):
     dev = raw["T_init"].device
     loss_fn = loss_fn or {"name": "huber", "metric": 1.0}
-    params = dict(params, dropout=0.0, max_iter=max_iter, icp_type="pt2pl", icp_loss_fn=loss_fn)
+    params = dict(params, dropout=0.0, max_iter=max_iter, icp_type="pt2pl", icp_loss_fn=loss_fn, icp_dim=dim)
     torch.manual_seed(seed)
     model = LearnICPWeightPolicy(params).to(dev)
     assert model.unet_backend == "hip"
@@ -45,7 +45,7 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     cb = {"fft_data": batch["loc_data"]["fft_data"].cpu(), "raw_pc": batch["loc_data"]["raw_pc"].cpu(),
           "filtered_pc": batch["loc_data"]["filtered_pc"].cpu(), "map_pc": raw["map_pc"].cpu(),
           "T_init": raw["T_init"].cpu(), "T_gt": raw["T_gt"].cpu()}
-    ref = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn=loss_fn, max_iter=max_iter, dim=2, dropout=0.0, seed=seed)
+    ref = train_ref.TrainStepRef(icp_type="pt2pl", loss_fn=loss_fn, max_iter=max_iter, dim=dim, dropout=0.0, seed=seed)
     ref.sd = sd
     x = unet_ref.assemble_input(cb["fft_data"])
     with torch.set_grad_enabled(backward):
@@ -56,7 +56,7 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     with torch.set_grad_enabled(backward):
         w = train_ref.gather_weights(mh, cb["raw_pc"])
         icp = ref.icp if backward else type(ref.icp)("pt2pl", differentiable=False, max_iterations=max_iter, tolerance=1e-5)
-        out = icp.icp(cb["filtered_pc"], cb["map_pc"], T_init=cb["T_init"], weight=w, trim_dist=5.0, loss_fn=loss_fn, dim=2)
+        out = icp.icp(cb["filtered_pc"], cb["map_pc"], T_init=cb["T_init"], weight=w, trim_dist=5.0, loss_fn=loss_fn, dim=dim)
     mism = 0
     if backward:
         for k in range(out["num_iter"]):
@@ -69,8 +69,13 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     res["idx_mismatches"] = mism
     res["icp_iters"] = out["num_iter"]
     Tg, Tr = T.detach().cpu().numpy().astype(np.float64), out["T"].detach().numpy().astype(np.float64)
-    res["pose_trans_err"] = float(np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max())
-    res["pose_rot_err"] = float(np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max())
+    res["pose_trans_err"] = float(np.abs(Tg[:, :dim, 3] - Tr[:, :dim, 3]).max())
+    if dim == 2:
+        res["pose_rot_err"] = float(np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max())
+    else:       # SE(3): angle of the relative rotation R_hip R_ref^T (from its skew part: exact for small angles)
+        Rd = Tg[:, :3, :3] @ np.transpose(Tr[:, :3, :3], (0, 2, 1))
+        skew = 0.5 * np.stack([Rd[:, 2, 1] - Rd[:, 1, 2], Rd[:, 0, 2] - Rd[:, 2, 0], Rd[:, 1, 0] - Rd[:, 0, 1]], axis=1)
+        res["pose_rot_err"] = float(np.arcsin(np.clip(np.linalg.norm(skew, axis=1), 0.0, 1.0)).max())
     if not backward:
         return res
     loss_d, _ = train_ref.eval_training_loss(out["T"], mh, None, cb["T_gt"], cb["fft_data"], None, cb["map_pc"], None, lw)
@@ -90,7 +95,7 @@ def run(raw, params, batch, max_iter, seed=1234, backward=True, loss_fn=None):
     res["mask_grad_taps_scale"] = float(np.abs(gm_ref)[sel].max())
     # ---------------- oracle end to end (fp32 network): the bf16 budget of the parameter gradients
     w2 = train_ref.gather_weights(mask_ref, cb["raw_pc"])
-    out2 = ref.icp.icp(cb["filtered_pc"], cb["map_pc"], T_init=cb["T_init"], weight=w2, trim_dist=5.0, loss_fn=loss_fn, dim=2)
+    out2 = ref.icp.icp(cb["filtered_pc"], cb["map_pc"], T_init=cb["T_init"], weight=w2, trim_dist=5.0, loss_fn=loss_fn, dim=dim)
     loss_r, _ = train_ref.eval_training_loss(out2["T"], mask_ref, None, cb["T_gt"], cb["fft_data"], None, cb["map_pc"], None, lw)
     loss_r.backward()
     gp = dict(model.named_parameters())

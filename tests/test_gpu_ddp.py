@@ -37,7 +37,7 @@ def _step(rank, world, global_batch, global_minmax):
     sync = ddp.FlatGradSync(model)
     sync.sync_params(0)
     idx = ddp.shard_indices(global_batch, rank, world)
-    raw = synthetic.make_batch(idx, device=dev, m_valid=3000, m_pad=3072)
+    raw = synthetic.make_batch(idx, device=dev, m_valid=3000, m_pad=3072, density="sparse")
     # make the shards' value ranges differ, so that a per-rank normalisation would be visible
     raw["fft_polar"] = raw["fft_polar"] * (1.0 - 0.3 * (torch.arange(len(idx), device=dev) % 2).view(-1, 1, 1) * (rank + 1) / world)
     batch = trn.prepare_batch(raw, params, max_loc_pts=2048)
@@ -83,7 +83,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_global_batch():
     model = LearnICPWeightPolicy(params).to(dev)
     model.train()
     sync = ddp.FlatGradSync(model)
-    raw = synthetic.make_batch(list(range(gb)), device=dev, m_valid=3000, m_pad=3072)
+    raw = synthetic.make_batch(list(range(gb)), device=dev, m_valid=3000, m_pad=3072, density="sparse")
     fac = T.ones(gb, device=dev)
     for r in range(world):
         for j, i in enumerate(ddp.shard_indices(gb, r, world)):

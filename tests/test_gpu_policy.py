@@ -128,7 +128,7 @@ def test_unet_hip_golden_640(golden_dir):
 
 
 def _small_batch(B=2, max_pts=2048, m_valid=3000):
-    raw = synthetic.make_batch(list(range(B)), device=DEV, m_valid=m_valid, m_pad=3072)
+    raw = synthetic.make_batch(list(range(B)), device=DEV, m_valid=m_valid, m_pad=3072, density="sparse")   # reduced sizes: the sparse scenes
     params = _params(icp_type="pt2pl", icp_loss_fn={"name": "huber", "metric": 1.0}, max_iter=5)
     return raw, params, trn.prepare_batch(raw, params, max_loc_pts=max_pts)
 
@@ -330,8 +330,8 @@ def test_fit_epoch_loop_and_resume(tmp_path):
         torch.manual_seed(11)
         model = LearnICPWeightPolicy(params).to(DEV)
         opt = trn.make_optimizer(model, params)
-        tr_it = trn.SyntheticIterator(params, 2, 2, max_loc_pts=2048, m_valid=3000, m_pad=3072)
-        va_it = trn.SyntheticIterator(params, 2, 1, dataset_type="test", max_loc_pts=2048, m_valid=3000, m_pad=3072, start=100)
+        tr_it = trn.SyntheticIterator(params, 2, 2, max_loc_pts=2048, m_valid=3000, m_pad=3072, density="sparse")
+        va_it = trn.SyntheticIterator(params, 2, 1, dataset_type="test", max_loc_pts=2048, m_valid=3000, m_pad=3072, density="sparse", start=100)
         start, best = (0, None)
         if resume:
             start, best = trn.load_checkpoint(os.path.join(ckdir, "resume.pt"), model, opt, map_location=DEV)

@@ -18,10 +18,10 @@ N_PAD, M_VALID, M_PAD = 5120, 20000, 20480
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
-def _batch(B, first):
+def _batch(B, first, dim=2):
     params = trn.default_params(DEV)
     params.update({"dropout": 0.0})
-    raw = synthetic.make_batch(list(range(first, first + B)), device=DEV, m_valid=M_VALID, m_pad=M_PAD)
+    raw = synthetic.make_batch(list(range(first, first + B)), device=DEV, m_valid=M_VALID, m_pad=M_PAD, dim=dim)
     return raw, params, trn.prepare_batch(raw, params, max_loc_pts=N_PAD)
 
 
@@ -46,6 +46,9 @@ def test_config1_b16_forward_parity():
 
 def test_config2_b32_full_step_parity():
     raw, params, batch = _batch(32, 3000)
+    # "N=5120 pad (~3 500-5 000 valid)" -- the synthetic scenes are inside that range
+    valid = (batch["loc_data"]["filtered_pc"] != 0).any(dim=-1).sum(dim=1).float()
+    assert 3500 <= float(valid.mean()) <= 5000 and float(valid.max()) <= N_PAD, valid
     res = step_parity.run(raw, params, batch, max_iter=10, backward=True)
     _record("config2", res)
     assert res["mask_max_abs"] < 4e-3, res
@@ -54,4 +57,19 @@ def test_config2_b32_full_step_parity():
     assert res["loss_rel_err"] < 1e-4, res
     assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
     # parameter gradients, bf16 storage vs fp32 (stated budget; measured 0.036 / 0.979: DESIGN.md §5b)
+    assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
+
+
+def test_config2_dim3_full_step_parity():
+    """SURVEY.md §8d config 3's `dim=3` / 6x6 variant driven through the POLICY (params["icp_dim"] = 3 -> the call site
+    /root/reference/mm_masking/icp_weight_policy.py:281-287 with dim=3): B=32, N=5120, M=20480, point-to-plane Huber, SE(3)
+    Gauss-Newton on a 3-D map (heights + tilted normals), whole step forward + backward against the oracle."""
+    raw, params, batch = _batch(32, 3000, dim=3)
+    res = step_parity.run(raw, params, batch, max_iter=10, backward=True, dim=3)
+    _record("config2_dim3", res)
+    assert res["mask_max_abs"] < 4e-3, res
+    assert res["idx_mismatches"] == 0 and res["icp_iters"] == 10, res
+    assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
+    assert res["loss_rel_err"] < 1e-4, res
+    assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
     assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
