@@ -131,8 +131,20 @@ class ICPWeightDataset(torch.utils.data.Dataset):
 
     The per-item work is the reference's: PNG rows -> load_radar, zero / target_pad_val padding to the largest
     cloud of the set, map filtering by elevation and normal, rotation augmentation, polar -> Cartesian (HIP
-    kernels through radar_utils; the CFAR cache is written with cfar_mask's HIP kernel).  Use it with
-    ``DataLoader(..., num_workers=0)``: the items touch the GPU.
+    kernels through radar_utils; the CFAR cache is written with cfar_mask's HIP kernel).
+
+    Two item modes:
+      * default (``params["batched_prepare"]`` absent / False): ``__getitem__`` returns the reference's finished item -- for a
+        Cartesian network that is one batch-1 polar -> Cartesian launch per item on the GPU, so such a Dataset is used with
+        ``DataLoader(..., num_workers=0)``;
+      * ``params["batched_prepare"] = True`` (what keeps a ~10 ms training step fed; the reference runs its per-item work in
+        4 DataLoader workers, train_icp_weights.py:454-455): ``__getitem__`` is CPU-ONLY and safe for ``num_workers=4`` --
+        decoded PNG rows (from a decoded-byte cache beside the CFAR cache: PNG inflate is ~10 ms per scan), load_radar's
+        azimuths, clouds, padding, map filtering, augmentation -- and leaves the images as uint8 polar rows
+        (``fft_u8``, ``cfar_u8``, ``azimuths`` in ``loc_data``); ``finish_batch`` then does bytes / 255 and ONE batched
+        polar -> Cartesian launch for the whole batch on the device.  ``DeviceLoader`` wraps both steps and stages batch
+        i + 1 on a side stream while batch i trains.  Finished batches are equal to ``default_collate`` of the default
+        mode's items (tests/test_round3_cpu.py, tests/test_gpu_round3.py).
     """
 
     def __init__(self, loc_pairs, params=None, dataset_type="train", data_dir="../data"):
@@ -163,6 +175,8 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         else:
             raise ValueError("Invalid sensor combination")
         self.data_dir = data_dir
+        self.batched_prepare = bool(params.get("batched_prepare", False))
+        self.decoded_cache = bool(params.get("decoded_cache", self.batched_prepare))
         self.polar_res = 0.0596
         self.samples = []                 # (pair index, loc_stamp, map_stamp)
         self.pair_dirs, self.T_map_sensor_robot = [], []
@@ -255,6 +269,8 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         T_ml_gt = self.T_loc_gt[index]
         scan_pc_raw, scan_pc_filt, map_pc, loc_stamp, map_stamp = self.load_graph_data(index, T_ml_gt)
         assert scan_pc_raw.shape == scan_pc_filt.shape, "Raw and filtered pointclouds dont match!"
+        if self.batched_prepare and not (self.map_sensor == "lidar" and self.loc_sensor == "lidar"):
+            return self._cpu_item(index, T_init, T_ml_gt, scan_pc_raw, scan_pc_filt, map_pc, loc_stamp, map_stamp)
         if not (self.map_sensor == "lidar" and self.loc_sensor == "lidar"):
             fft_data, azimuths, _ = ru.load_radar(read_png_gray(self.loc_radar_path_list[index]))
             fft_data = torch.tensor(fft_data, dtype=self.float_type)
@@ -274,8 +290,196 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         map_data = {"pc": map_pc, "timestamp": map_stamp}
         return {"loc_data": loc_data, "map_data": map_data, "transforms": {"T_ml_init": T_init, "T_ml_gt": T_ml_gt}}
 
+    # -- worker-safe items (params["batched_prepare"])
+    def _decoded(self, png_path):
+        """Decoded rows of an 8-bit PNG, through a raw-byte cache next to the file (``<name>.png.u8`` = uint32 height, uint32
+        width, then the rows): inflating a 400 x 3371 Navtech scan costs ~10 ms of a worker's time, reading 1.3 MB from
+        the page cache ~0.2 ms.  Written once (atomically: several workers may race for the same file)."""
+        if not self.decoded_cache:
+            return read_png_gray(png_path)
+        cpath = png_path + ".u8"
+        try:
+            if os.path.getmtime(cpath) >= os.path.getmtime(png_path):
+                raw = np.memmap(cpath, dtype=np.uint8, mode="r")      # mapped, not read: the one copy is the caller's slice
+                h, w = np.frombuffer(raw[:8].tobytes(), dtype=np.uint32)
+                if raw.size == 8 + int(h) * int(w):
+                    return raw[8:].reshape(int(h), int(w))
+        except OSError:
+            pass
+        img = read_png_gray(png_path)
+        tmp = "%s.%d.tmp" % (cpath, os.getpid())
+        try:
+            with open(tmp, "wb") as f:
+                f.write(np.array(img.shape, dtype=np.uint32).tobytes())
+                f.write(np.ascontiguousarray(img).tobytes())
+            os.replace(tmp, cpath)
+        except OSError:
+            pass                      # read-only data directory: decode every time
+        return img
+
+    def _cpu_item(self, index, T_init, T_ml_gt, scan_pc_raw, scan_pc_filt, map_pc, loc_stamp, map_stamp):
+        """The CPU-only part of __getitem__ (icp_weight_dataset.py:336-348): no float image, no GPU call."""
+        raw = self._decoded(self.loc_radar_path_list[index])
+        # load_radar (radar_utils.py:20-27) without the float image: azimuths from the encoder bytes, power bytes kept as uint8
+        azimuths = torch.tensor(np.frombuffer(raw[:, 8:10].tobytes(), dtype=np.uint16) * (2 * np.pi / 5600), dtype=self.float_type)
+        fft_u8 = torch.from_numpy(np.array(raw[:, 11:], dtype=np.uint8, order="C"))
+        cfar_u8 = torch.from_numpy(np.array(self._decoded(self.loc_cfar_path_list[index]), dtype=np.uint8, order="C"))
+        if self.augment:
+            scan_pc_raw, scan_pc_filt, map_pc, azimuths, fft_u8, cfar_u8 = augment_data(
+                scan_pc_raw, scan_pc_filt, map_pc, azimuths, fft_u8, cfar_u8, self.float_type)
+        loc_data = {"raw_pc": scan_pc_raw, "filtered_pc": scan_pc_filt, "fft_u8": fft_u8, "cfar_u8": cfar_u8,
+                    "azimuths": azimuths, "timestamp": loc_stamp}
+        return {"loc_data": loc_data, "map_data": {"pc": map_pc, "timestamp": map_stamp},
+                "transforms": {"T_ml_init": T_init, "T_ml_gt": T_ml_gt}}
+
     def get_item_from_loc_timestamp(self, loc_stamp_req):
         """icp_weight_dataset.py:454-495."""
         index = [i for i, s in enumerate(self.samples) if s[1] == int(loc_stamp_req)]
         assert index != [], "loc_stamp_req not found in dataset"
         return self[index[0]]
+
+
+def finish_batch(batch, device, network_input_type="cartesian", float_type=torch.float32, polar_res=0.0596, non_blocking=True):
+    """Device half of the worker-safe loader: a collated batch of ``batched_prepare`` items -> the reference's batch
+    dictionary (icp_weight_dataset.py:357-362) with every tensor on ``device``.  bytes / 255 is load_radar's fp32 division
+    (radar_utils.py:26) and the CFAR cache's (icp_weight_dataset.py:343) done on the device; the polar -> Cartesian
+    resampling (icp_weight_dataset.py:351-352) is ONE batched launch instead of one per item."""
+    from . import radar_utils as ru
+    loc = batch["loc_data"]
+    if "fft_u8" not in loc:                      # already a finished (default-mode) batch: move it
+        to = lambda v: v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v   # noqa: E731
+        return {k: {kk: to(vv) for kk, vv in v.items()} for k, v in batch.items()}
+    fft = loc["fft_u8"].to(device, non_blocking=non_blocking).to(float_type) / 255.0
+    cfar = loc["cfar_u8"].to(device, non_blocking=non_blocking).to(float_type) / 255.0
+    az = loc["azimuths"].to(device, non_blocking=non_blocking)
+    if network_input_type == "cartesian":
+        fft, cfar = ru._polar_to_cart_pair(fft.contiguous(), cfar.contiguous(), az.contiguous(), polar_res)
+    to = lambda v: v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v       # noqa: E731
+    stamp = lambda v: v.clone() if torch.is_tensor(v) else v          # noqa: E731  (host tensors: not views of a re-used buffer)
+    return {"loc_data": {"raw_pc": to(loc["raw_pc"]), "filtered_pc": to(loc["filtered_pc"]), "fft_data": fft, "fft_cfar": cfar,
+                         "timestamp": stamp(loc["timestamp"])},
+            "map_data": {"pc": to(batch["map_data"]["pc"]), "timestamp": stamp(batch["map_data"]["timestamp"])},
+            "transforms": {k: to(v) for k, v in batch["transforms"].items()}}
+
+
+class DeviceLoader:
+    """``DataLoader(dataset, num_workers=4)`` (train_icp_weights.py:454-455) + ``finish_batch``: iterating yields the reference's
+    batch dictionaries on the device.  The per-item CPU work (``__getitem__`` of a ``batched_prepare`` Dataset) runs in
+    ``num_workers`` parallel workers; the main thread stages batch i + 1 (H2D copies, bytes / 255, one polar -> Cartesian
+    launch) on a side stream while the caller trains on batch i, and hands it over with a stream wait -- no host
+    synchronisation.
+
+    ``mode="threads"`` (default): the workers are threads of this process that write their item straight into the batch's
+    pinned host buffers -- the item is ~3.3 MB of byte rows whose handling (page-cache copy, roll, clone, filter) releases
+    the GIL, and a batch of 32 is ~105 MB, which worker PROCESSES would have to push through shared memory and the main
+    process's unpickling (measured 3-10x slower than the threads).  ``mode="processes"``: torch's DataLoader with
+    ``num_workers`` worker processes and pinned collation, as upstream.  Same batches either way (tests/test_round3_cpu.py)."""
+
+    def __init__(self, dataset, batch_size, device, num_workers=4, shuffle=False, drop_last=False, prefetch_factor=2,
+                 persistent_workers=True, mode="threads"):
+        if not getattr(dataset, "batched_prepare", False):
+            raise ValueError("DeviceLoader needs a Dataset built with params['batched_prepare'] = True (CPU-only items)")
+        if mode not in ("threads", "processes"):
+            raise ValueError("mode must be 'threads' or 'processes'")
+        self.dataset, self.device, self.mode = dataset, torch.device(device), mode
+        self.batch_size, self.shuffle, self.drop_last, self.num_workers = int(batch_size), shuffle, drop_last, int(num_workers)
+        self.loader = None
+        if mode == "processes" or num_workers == 0:
+            kw = {}
+            if num_workers > 0:
+                kw = {"prefetch_factor": prefetch_factor, "persistent_workers": persistent_workers}
+            self.loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
+                                                      drop_last=drop_last, pin_memory=self.device.type == "cuda", **kw)
+        self._side = None
+        self._pool = None
+        self._bufs = {}            # (slot, batch length) -> pinned batch buffers
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    # -- thread mode: items written in place into pinned batch buffers
+    def _batches(self):
+        n = len(self.dataset)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n, self.batch_size):
+            idx = order[i:i + self.batch_size]
+            if len(idx) < self.batch_size and self.drop_last:
+                return
+            yield idx
+
+    def _fill(self, bufs, j, index):
+        item = self.dataset[index]
+        for grp, d in item.items():
+            for k, v in d.items():
+                if torch.is_tensor(v):
+                    bufs[grp][k][j].copy_(v)
+                else:
+                    bufs[grp][k][j] = v
+        return None
+
+    def _assemble(self, slot, idx):
+        key = (slot, len(idx))
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            item = self.dataset[idx[0]]
+            pin = self.device.type == "cuda"
+            bufs = {grp: {k: (torch.empty((len(idx),) + tuple(v.shape), dtype=v.dtype, pin_memory=pin) if torch.is_tensor(v)
+                              else torch.empty(len(idx), dtype=torch.int64))
+                          for k, v in d.items()} for grp, d in item.items()}
+            self._bufs[key] = bufs
+        list(self._pool.map(lambda a: self._fill(bufs, a[0], a[1]), enumerate(idx)))
+        return bufs
+
+    def _cpu_batches(self):
+        if self.loader is not None:
+            yield from self.loader
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="mmk-loader")
+        # three slots: one being filled, one being copied to the device by the side stream, one handed to the caller's step
+        for n, idx in enumerate(self._batches()):
+            yield self._assemble(n % 3, idx)
+
+    def _stage(self, cpu_batch):
+        ds = self.dataset
+        if self.device.type != "cuda":
+            out = finish_batch(cpu_batch, self.device, ds.network_input_type, ds.float_type, ds.polar_res)
+            if self.loader is None:            # the slot buffers are re-used: hand out copies on a CPU device
+                out = {g: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for g, d in out.items()}
+            return out, None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._side):
+            out = finish_batch(cpu_batch, self.device, ds.network_input_type, ds.float_type, ds.polar_res)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self._cpu_batches())
+        try:
+            staged = self._stage(next(it))
+        except StopIteration:
+            return
+        while staged is not None:
+            batch, ev = staged
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for grp in batch.values():                 # memory allocated on the side stream, consumed on the caller's
+                    for v in grp.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(cur)
+            # assemble + stage the next batch BEFORE handing this one over: its copies overlap the caller's step.  A pinned
+            # slot is rewritten two batches later, after the side stream's copies out of it have completed (the event above
+            # of the batch in between has been waited for by then only on the GPU: synchronise on it host-side).
+            try:
+                nxt = next(it)
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                ev.synchronize()
+            staged = self._stage(nxt) if nxt is not None else None
+            yield batch

@@ -1,0 +1,77 @@
+"""Round-3 CPU tests: the worker-safe loader.  ``ICPWeightDataset`` with
+``params["batched_prepare"]`` returns CPU-only items (uint8 polar rows, azimuths, clouds) that a
+``DataLoader(num_workers=4)`` can produce in parallel, as the reference does
+(/root/reference/mm_masking/train_icp_weights.py:454-455, icp_weight_dataset.py:323-362); ``finish_batch``
+turns a collated batch into the reference's batch dictionary.  Checked here on the polar network input
+(no HIP call) against the default item mode, which tests/test_round2_cpu.py pins to the reference's own
+``__getitem__`` output (tests/golden/dataset_item.npz)."""
+import os
+
+import numpy as np
+import torch
+
+from mm_masking_amd import icp_weight_dataset as ds
+
+from test_round2_cpu import _write_export, dataset_params
+
+
+def _same(a, b, path=""):
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), (path, a.keys(), b.keys())
+        for k in a:
+            _same(a[k], b[k], path + "/" + str(k))
+    elif torch.is_tensor(a):
+        assert a.dtype == b.dtype and torch.equal(a, b), path
+    else:
+        assert a == b, path
+
+
+def test_worker_items_finish_to_the_reference_batch(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
+    pairs = _write_export(str(tmp_path), g)
+    ref = ds.ICPWeightDataset(pairs, dataset_params(), dataset_type="train", data_dir=str(tmp_path))
+    wrk = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
+    wrk.T_loc_init = ref.T_loc_init.clone()
+    want = next(iter(torch.utils.data.DataLoader(ref, batch_size=2, shuffle=False, num_workers=0)))
+    it = wrk[0]
+    assert it["loc_data"]["fft_u8"].dtype == torch.uint8 and it["loc_data"]["azimuths"].dtype == torch.float32
+    assert "fft_data" not in it["loc_data"]                                   # nothing float, nothing on a device
+    # four worker processes, as upstream; twice: the second pass reads the decoded-byte cache the first one wrote
+    for rep in range(2):
+        got = next(iter(torch.utils.data.DataLoader(wrk, batch_size=2, shuffle=False, num_workers=4)))
+        fin = ds.finish_batch(got, "cpu", network_input_type="polar")
+        _same(fin, want)
+        assert os.path.exists(wrk.loc_radar_path_list[0] + ".u8") and os.path.exists(wrk.loc_cfar_path_list[0] + ".u8")
+    # the items of the default mode equal the reference's own (test_round2_cpu.py); spot-check the chain here too
+    assert np.array_equal(fin["loc_data"]["fft_data"][0].numpy(), g["p0_fft_sub"])
+    # a stale cache (older than its PNG) is ignored and rewritten
+    cpath = wrk.loc_radar_path_list[1] + ".u8"
+    with open(cpath, "wb") as f:
+        f.write(b"\x00" * 16)
+    os.utime(cpath, (1, 1))
+    _same(ds.finish_batch(torch.utils.data.default_collate([wrk[0], wrk[1]]), "cpu", network_input_type="polar"), want)
+    assert os.path.getsize(cpath) > 16
+    # DeviceLoader on a CPU device: same batches, in order
+    for mode in ("threads", "processes"):
+        dl = ds.DeviceLoader(wrk, batch_size=1, device="cpu", num_workers=2, mode=mode)
+        got = list(dl)
+        assert len(got) == len(dl) == 2
+        _same(torch.utils.data.default_collate([ref[0]]), got[0])
+        _same(torch.utils.data.default_collate([ref[1]]), got[1])
+    _same(want, next(iter(ds.DeviceLoader(wrk, batch_size=2, device="cpu", num_workers=4))))
+
+
+def test_worker_items_augmentation_matches_default_mode(golden_dir, tmp_path):
+    """Same yaw draw -> same rolled rows, azimuths and rotated clouds in both item modes (icp_weight_dataset.py:425-452)."""
+    g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
+    pairs = _write_export(str(tmp_path), g)
+    ref = ds.ICPWeightDataset(pairs, dataset_params(augment=True), dataset_type="train", data_dir=str(tmp_path))
+    wrk = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train",
+                              data_dir=str(tmp_path))
+    wrk.T_loc_init = ref.T_loc_init.clone()
+    for i in range(2):
+        torch.manual_seed(77 + i)
+        a = ref[i]
+        torch.manual_seed(77 + i)
+        b = ds.finish_batch(torch.utils.data.default_collate([wrk[i]]), "cpu", network_input_type="polar")
+        _same(torch.utils.data.default_collate([a]), b)
