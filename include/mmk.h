@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 210 /* 0.2.1: + mmk_conv_bwd_fused, mmk_conv8x16_bwd_fused, mmk_conv16x8_bwd_fused */
+#define MMK_VERSION 300 /* 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -175,11 +175,15 @@ int mmk_sample_weights_fwd(const float *mask /*B,H,W*/, const float *pc /*B,N,pc
                            int32_t B, int32_t N, int32_t pc_cols, int32_t H, int32_t W,
                            int32_t cart_pixel_width, float cart_resolution,
                            float *weights /*B,N*/, void *stream);
-/* grad_mask (B,H,W) is zero-filled here, then receives the scatter-add. */
+/* grad_mask (B,H,W) is zero-filled here, then receives the scatter-add -- in a FIXED order: the taps that fall on one
+ * pixel are chained (integer exchanges), and the chain's owner adds them in ascending (point, tap) order, which is
+ * the order of a sequential loop over the points (what PyTorch's CPU grid_sample backward does): no float atomics,
+ * bit-reproducible.  ws: mmk_sample_weights_bwd_ws_bytes(B, N) bytes. */
+size_t mmk_sample_weights_bwd_ws_bytes(int32_t B, int32_t N);
 int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, int32_t B,
                            int32_t N, int32_t pc_cols, int32_t H, int32_t W,
                            int32_t cart_pixel_width, float cart_resolution, float *grad_mask,
-                           void *stream);
+                           void *ws, size_t ws_bytes, void *stream);
 
 /* Statistics extract_weights returns next to the weights (radar_utils.py:130-138) and the policy's
  * mean_all_pts (icp_weight_policy.py:209-212), over the real points (not x==0 && y==0):
@@ -240,16 +244,9 @@ int mmk_conv3x3_pack_weights(const float *W, int32_t cout, int32_t cin, int32_t 
 int mmk_conv3x3_pack_weights_batch(int32_t n, const float *const *W, const int32_t *cout, const int32_t *cin,
                                    int32_t transposed, void *const *packed, void *stream);
 int mmk_conv3x3(const mmk_conv_desc *d, void *stream);
-/* Weight + bias gradient of the same convolution (autograd of nn.Conv2d,
- * train_icp_weights.py:51): dWt[tap][cout][cin] += sum_pixels g * shifted input, db[cout] += sum g
- * (fp32, caller zero-initialises; float atomics).  g = gradient w.r.t. the pre-activation.
- * mmk_conv3x3_wgrad_unpack writes / accumulates it into the parameter's [cout][cin][3][3] layout. */
-int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
-                      int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream);
-int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
-                             void *stream);
-/* Partial-sum form of the weight gradient (mmk_conv3x3_wgrad_slices() = number of slices for a shape on the
- * current device, 0 = unsupported shape): every workgroup stores its own slice of `partials`
+/* Weight + bias gradient of the same convolution (autograd of nn.Conv2d, train_icp_weights.py:51), g = gradient
+ * w.r.t. the pre-activation, as per-workgroup partial sums (mmk_conv3x3_wgrad_slices() = number of slices for a shape
+ * on the current device, 0 = unsupported shape): every workgroup stores its own slice of `partials`
  * (slices, 9*cout*cin + cout) -- the (9,cout,cin) weight sums followed by the cout bias sums -- with plain
  * stores (accumulate != 0: adds to it -- second application of shared weights) and
  * mmk_conv3x3_wgrad_unpack_batch sums the slices: no float atomics, bit-reproducible. */
@@ -301,8 +298,11 @@ int mmk_channel_minmax(const float *x /*B,C,hw*/, int32_t B, int32_t C, int64_t 
                        float *pre /*C*2*/, float *minmax /*C*2 or NULL*/, void *stream);
 int mmk_conv_first(const float *x, int32_t cin, const float *W, const float *bias, const float *pre,
                    int32_t B, int32_t H, int32_t Wd, float leaky_slope, void *y, void *stream);
+/* dW[8][cin][3][3] and db[8] are WRITTEN (not added to): per-block partial sums into ws, then one ordered reduction --
+ * no float atomics, bit-reproducible.  ws: mmk_conv_first_wgrad_ws_bytes(cin) bytes. */
+size_t mmk_conv_first_wgrad_ws_bytes(int32_t cin);
 int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B,
-                         int32_t H, int32_t Wd, float *dW, float *db, void *stream);
+                         int32_t H, int32_t Wd, float *dW, float *db, float *ws, size_t ws_bytes, void *stream);
 
 /* nn.MaxPool2d(2,2) on NHWC bf16 (icp_weight_policy.py:122-123).  _bwd fuses the backward of
  * the preceding Dropout(ReLU(.)): gz = route(gy) * (d > 0 ? scale : 0), d = the pooled tensor's
@@ -320,21 +320,23 @@ int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t Ws, int32_t 
                      const void *relu_src, float scale, float leaky_slope, void *gx, void *stream);
 
 /* final_layer: Conv2d(8,1,1x1) + Sigmoid (icp_weight_policy.py:96-99,184): bf16 (npix,8) -> fp32
- * mask (npix).  _bwd: gx = dL/dx * (x > 0 ? scale : 0) (bf16), dW[8] +=, db[1] +=.            */
+ * mask (npix).  _bwd: gx = dL/dx * (x > 0 ? scale : 0) (bf16); dW[8] and db[1] are WRITTEN: per-block partial
+ * sums into ws (MMK_FINAL_BWD_WS_FLOATS floats), then one ordered reduction -- no float atomics.  */
+#define MMK_FINAL_BWD_WS_FLOATS 16384
 int mmk_final_fwd(const void *x, const float *w, const float *bias, int64_t npix, float *mask, void *stream);
 int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
-                  float leaky_slope, void *gx, float *dW, float *db, void *stream);
+                  float leaky_slope, void *gx, float *dW, float *db, float *ws, void *stream);
 /* mask_n = mask / amax(mask over the image) per image (icp_weight_policy.py:192-193), amax (B) out;
  * part: B*64 floats of workspace. */
 int mmk_mask_normalize(const float *mask /*B,npix_per*/, int32_t B, int64_t npix_per, float *part,
                        float *mask_n, float *amax, void *stream);
 /* mmk_final_bwd for a mask that went through mmk_mask_normalize: gmask_n is the gradient w.r.t.
  * mask_n; the adjoint of the division and of amax (spread evenly over tied maxima, as torch.amax)
- * is applied on the fly.  part: B*128 floats, coef: 2*B floats of workspace. */
+ * is applied on the fly.  part: B*128 floats, coef: 2*B floats, ws: MMK_FINAL_BWD_WS_FLOATS floats of workspace. */
 int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n,
                              const float *amax, const float *gmask_n, int32_t B, int64_t npix_per,
                              float scale, float leaky_slope, float *part, float *coef, void *gx, float *dW,
-                             float *db, void *stream);
+                             float *db, float *ws, void *stream);
 
 /* nn.BatchNorm2d of the network's batch-norm variant (params["batch_norm"], icp_weight_policy.py:108-113) on NHWC
  * bf16 (npix, C).  _forward_stats: batch statistics -> stat (C,2) = (mean, 1/sqrt(var + eps)) and affine (C,2) =

@@ -59,26 +59,42 @@ class UNetDesc(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("mask", ctypes.c_void_p)]
 
 
+FINAL_BWD_WS_FLOATS = 16384        # MMK_FINAL_BWD_WS_FLOATS of include/mmk.h
 ICP_TYPES = {"pt2pt": 0, "pt2pl": 1}
 LOSSES = {None: 0, "none": 0, "l2": 0, "cauchy": 1, "huber": 2}
 NN_METHODS = {"brute": 0, "grid": 1}
 
 
 def build(verbose=False):
-    """Compile the HIP sources for gfx950 into mm_masking_amd/libmmk_hip.so
-    (hipcc cross-compiles without a GPU).  -ffp-contract=off is part of the
-    numerical contract."""
-    srcs = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(_HERE, "csrc", "mmk_common.h"), os.path.join(_HERE, "csrc", "mmk_conv_ring_stage.inc"),
-                   os.path.join(_ROOT, "include", "mmk.h")]
-    if os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
-        return SO_PATH
+    """Compile the HIP sources for gfx950 into mm_masking_amd/libmmk_hip.so (hipcc cross-compiles without a GPU): one
+    object per source (in parallel, only the stale ones), then one link.  -ffp-contract=off is part of the numerical
+    contract."""
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, s) for s in SOURCES]
+    common = [os.path.join(csrc, "mmk_common.h"), os.path.join(_ROOT, "include", "mmk.h")]
+    extra = {"mmk_unet.hip": [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".inc")]}
+    objdir = os.path.join(csrc, "_obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-I", os.path.join(_ROOT, "include"), "-o", SO_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        deps = [src] + common + extra.get(os.path.basename(src), [])
+        if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(o) for o in objs):
+        return SO_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs)
     return SO_PATH
 
 
@@ -101,8 +117,6 @@ def _declare(lib):
         "mmk_conv3x3_pack_weights": (ctypes.c_int, [c_vp, i32, i32, i32, c_vp, c_vp]),
         "mmk_conv3x3_pack_weights_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
         "mmk_conv3x3": (ctypes.c_int, [ctypes.POINTER(ConvDesc), c_vp]),
-        "mmk_conv3x3_wgrad": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
-        "mmk_conv3x3_wgrad_unpack": (ctypes.c_int, [c_vp, i32, i32, i32, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_unpack_batch": (ctypes.c_int, [i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv3x3_wgrad_slices": (i32, [i32, i32, i32, i32, i32, i32]),
         "mmk_conv3x3_wgrad_partial": (ctypes.c_int, [c_vp, c_vp, i32, i32, c_vp, i32, i32, i32, i32, c_vp, i32, c_vp]),
@@ -112,16 +126,17 @@ def _declare(lib):
         "mmk_conv3x3_pool_fusable": (ctypes.c_int32, [i32, i32, i32, i32, i32]),
         "mmk_channel_minmax": (ctypes.c_int, [c_vp, i32, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_conv_first": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, i32, f32, c_vp, c_vp]),
-        "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
+        "mmk_conv_first_wgrad_ws_bytes": (sz, [i32]),
+        "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp, sz, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_maxpool2_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, f32, c_vp, c_vp]),
         "mmk_upsample_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_upsample_bwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, f32, f32, c_vp, c_vp]),
         "mmk_final_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
-        "mmk_final_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, f32, f32, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_final_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_mask_normalize": (ctypes.c_int, [c_vp, i32, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp]),
         "mmk_final_bwd_normalized": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, ctypes.c_int64, f32, f32, c_vp, c_vp,
-                                                    c_vp, c_vp, c_vp, c_vp]),
+                                                    c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_bn_forward_stats": (ctypes.c_int, [c_vp, ctypes.c_int64, i32, c_vp, c_vp, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "mmk_bn_apply": (ctypes.c_int, [c_vp, ctypes.c_int64, i32, c_vp, f32, ctypes.c_uint32, c_vp, c_vp]),
         "mmk_bn_backward": (ctypes.c_int, [c_vp, c_vp, f32, c_vp, ctypes.c_int64, i32, c_vp, c_vp, c_vp, f32, i32, c_vp, c_vp, c_vp,
@@ -141,7 +156,8 @@ def _declare(lib):
                                                   c_vp]),
         "mmk_cart_to_polar": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, i32, ctypes.c_double, c_vp, c_vp]),
         "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
-        "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
+        "mmk_sample_weights_bwd_ws_bytes": (sz, [i32, i32]),
+        "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp, sz, c_vp]),
         "mmk_weight_stats": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
         "mmk_bev_raster": (ctypes.c_int, [c_vp, i32, i32, i32, i32, f32, c_vp, c_vp]),
     }

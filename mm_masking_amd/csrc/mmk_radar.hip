@@ -372,22 +372,79 @@ __global__ void sample_weights_fwd_kernel(const float *__restrict__ mask, const 
                              tap(t.yi + 1, t.xi + 1) * t.w11;
 }
 
-__global__ void sample_weights_bwd_kernel(const float *__restrict__ gw, const float *__restrict__ pc, int N, int cols,
-                                          int H, int W, int cw, float cres, float *__restrict__ gmask)
+// Backward of the gather = scatter-add of g * w into the four taps of every point, WITHOUT float atomics (their order of
+// arrival would make the mask gradient differ from run to run where several taps fall on one pixel: neighbouring
+// azimuths near the sensor, neighbouring peaks of one azimuth).  Three passes over the 4 N entries e = 4 n + q of an image:
+//   link   every in-image entry pushes itself on its pixel's chain with an INTEGER exchange on the (zero-filled)
+//          gradient word itself: head = e + 1, next[e] = previous head - 1 (0 = empty -> -1).  The chain's ORDER
+//          depends on arrival; its SET of entries does not.
+//   sum    every entry walks its pixel's chain; the entry with the lowest index owns the pixel and adds the chain's
+//          values in ascending entry order (repeated selection of the next-larger index: chains are short) -- the order
+//          of a sequential loop over points and taps, as PyTorch's CPU grid_sample backward runs it.
+//   store  the owners write the sums over the chain heads.
+__device__ __forceinline__ int tap_pixel(const Taps &t, int q, int H, int W, float &w)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = t.yi + (q >> 1), xx = t.xi + (q & 1);
+    w = q == 0 ? t.w00 : (q == 1 ? t.w01 : (q == 2 ? t.w10 : t.w11));
+    return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? yy * W + xx : -1;
+}
+
+__global__ void sample_weights_bwd_link_kernel(const float *__restrict__ gw, const float *__restrict__ pc, int N, int cols,
+                                               int H, int W, int cw, float cres, float *__restrict__ gmask,
+                                               int *__restrict__ next, float *__restrict__ val, int *__restrict__ pix)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
-    if (n >= N) return;
+    if (e >= 4 * N) return;
+    const int n = e >> 2, q = e & 3;
     const Taps t = weight_taps(pc + ((size_t)b * N + n) * cols, H, W, cw, cres);
-    const float g = gw[(size_t)b * N + n];
-    float *m = gmask + (size_t)b * H * W;
-    auto put = [&](int yy, int xx, float w) {
-        if (xx >= 0 && xx < W && yy >= 0 && yy < H) atomicAdd(&m[(size_t)yy * W + xx], g * w);
-    };
-    put(t.yi, t.xi, t.w00);
-    put(t.yi, t.xi + 1, t.w01);
-    put(t.yi + 1, t.xi, t.w10);
-    put(t.yi + 1, t.xi + 1, t.w11);
+    float w;
+    const int p = tap_pixel(t, q, H, W, w);
+    const size_t o = (size_t)b * 4 * N + e;
+    pix[o] = p;
+    if (p < 0) return;
+    val[o] = gw[(size_t)b * N + n] * w;
+    int *head = reinterpret_cast<int *>(gmask + (size_t)b * H * W + p);
+    next[o] = atomicExch(head, e + 1) - 1;
+}
+
+__global__ void sample_weights_bwd_sum_kernel(int N, int H, int W, const float *__restrict__ gmask, const int *__restrict__ next,
+                                              const float *__restrict__ val, int *__restrict__ pix, float *__restrict__ res)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= 4 * N) return;
+    const size_t base = (size_t)b * 4 * N;
+    const int p = pix[base + e];
+    if (p < 0) return;
+    const int head = reinterpret_cast<const int *>(gmask + (size_t)b * H * W)[p] - 1;
+    // the owner is the chain's lowest entry index
+    int lo = head, len = 0;
+    for (int c = head; c >= 0 && len < 4 * N; c = next[base + c], ++len) lo = c < lo ? c : lo;
+    if (lo != e) {
+        pix[base + e] = -1;                    // not the owner: nothing to store
+        return;
+    }
+    float sum = 0.f;
+    int last = -1;
+    for (int k = 0; k < len; ++k) {            // the next-larger index, len times: ascending order of the entries
+        int pick = 0x7fffffff;
+        for (int c = head, j = 0; c >= 0 && j < len; c = next[base + c], ++j)
+            if (c > last && c < pick) pick = c;
+        sum += val[base + pick];
+        last = pick;
+    }
+    res[base + e] = sum;
+}
+
+__global__ void sample_weights_bwd_store_kernel(int N, int H, int W, const int *__restrict__ pix, const float *__restrict__ res,
+                                                float *__restrict__ gmask)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= 4 * N) return;
+    const int p = pix[(size_t)b * 4 * N + e];
+    if (p >= 0) gmask[(size_t)b * H * W + p] = res[(size_t)b * 4 * N + e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -622,17 +679,35 @@ extern "C" int mmk_sample_weights_fwd(const float *mask, const float *pc, int32_
     return MMK_OK;
 }
 
+extern "C" size_t mmk_sample_weights_bwd_ws_bytes(int32_t B, int32_t N)
+{
+    return B < 1 || N < 1 ? 0 : (size_t)B * N * 4 * 4 * sizeof(float);       // next | val | pix | res, one word per (point, tap) each
+}
+
 extern "C" int mmk_sample_weights_bwd(const float *grad_weights, const float *pc, int32_t B, int32_t N, int32_t pc_cols,
                                       int32_t H, int32_t W, int32_t cart_pixel_width, float cart_resolution,
-                                      float *grad_mask, void *stream)
+                                      float *grad_mask, void *ws, size_t ws_bytes, void *stream)
 {
-    MMK_REQUIRE(grad_weights && pc && grad_mask, "mmk_sample_weights_bwd: NULL pointer");
+    MMK_REQUIRE(grad_weights && pc && grad_mask && ws, "mmk_sample_weights_bwd: NULL pointer");
     MMK_REQUIRE(B >= 1 && N >= 1 && pc_cols >= 2 && H >= 2 && W >= 2 && cart_pixel_width >= 2,
                 "mmk_sample_weights_bwd: bad shape");
+    MMK_REQUIRE((size_t)N * 4 < ((size_t)1 << 30) && (size_t)H * W < ((size_t)1 << 31), "mmk_sample_weights_bwd: shape too large");
+    MMK_REQUIRE(ws_bytes >= mmk_sample_weights_bwd_ws_bytes(B, N), "mmk_sample_weights_bwd: workspace too small (%zu < %zu bytes)",
+                ws_bytes, mmk_sample_weights_bwd_ws_bytes(B, N));
     hipStream_t st = (hipStream_t)stream;
+    const size_t ne = (size_t)B * N * 4;
+    int *next = static_cast<int *>(ws);
+    float *val = reinterpret_cast<float *>(next + ne);
+    int *pix = reinterpret_cast<int *>(val + ne);
+    float *res = reinterpret_cast<float *>(pix + ne);
     MMK_CHECK_HIP(hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * H * W, st));
-    hipLaunchKernelGGL(sample_weights_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, grad_weights, pc, N, pc_cols,
-                       H, W, cart_pixel_width, cart_resolution, grad_mask);
+    const dim3 grid((4 * N + 255) / 256, B);
+    hipLaunchKernelGGL(sample_weights_bwd_link_kernel, grid, dim3(256), 0, st, grad_weights, pc, N, pc_cols, H, W, cart_pixel_width,
+                       cart_resolution, grad_mask, next, val, pix);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sample_weights_bwd_sum_kernel, grid, dim3(256), 0, st, N, H, W, grad_mask, next, val, pix, res);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sample_weights_bwd_store_kernel, grid, dim3(256), 0, st, N, H, W, pix, res, grad_mask);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

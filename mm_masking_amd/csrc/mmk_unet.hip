@@ -1247,10 +1247,8 @@ struct WgradArgs {
     const bf16 *x1, *x2;
     int C1, C2;
     const bf16 *g;   // (B,H,W,COUT)
-    float *dWt;      // [9][COUT][CIN]
-    float *db;       // [COUT] or null
     int B, H, W, CIN, COUT;
-    float *partials; // optional [gridDim.x][9][COUT][CIN]: per-block partial sums instead of atomics into dWt
+    float *partials; // [gridDim.x][9 * COUT * CIN + COUT]: per-block partial sums (weights, then bias), plain stores
     int acc_partials;   // add to what `partials` holds (second application of shared weights)
 };
 
@@ -1454,22 +1452,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
                     tap = 2 * nt + (i16 >> 3);
                     ci = i16 & 7;
                 }
-                if (tap < 9) {
-                    if (a.partials) {       // this block's own slice, plain stores (see the 8-wave kernel)
-                        float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * a.COUT + co) * a.CIN + ci;
-                        *d = a.acc_partials ? *d + acc[m][n][rr] : acc[m][n][rr];
-                    } else {
-                        atomicAdd(&a.dWt[((size_t)tap * a.COUT + co) * a.CIN + ci], acc[m][n][rr]);
-                    }
+                if (tap < 9) {          // this block's own slice, plain stores (see the 8-wave kernel)
+                    float *d = a.partials + (size_t)blockIdx.x * pstride + ((size_t)tap * a.COUT + co) * a.CIN + ci;
+                    *d = a.acc_partials ? *d + acc[m][n][rr] : acc[m][n][rr];
                 }
             }
-            if (wv == 0 && chunk == 0 && i16 == 0) {
-                if (a.partials) {           // bias partial: last COUT floats of the slice
-                    float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
-                    *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
-                } else if (a.db) {
-                    atomicAdd(&a.db[co], accb[m][rr]);
-                }
+            if (wv == 0 && chunk == 0 && i16 == 0) {      // bias partial: last COUT floats of the slice
+                float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
+                *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
             }
         }
     }
@@ -1992,9 +1982,10 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
         for (int rr = 0; rr < 4; ++rr) {
             const int co = group * CM + (wm * 2 + m) * 16 + g4 * 4 + rr;
             const int ci = chunk * CK + wc * 16 + i16;
-            if (a.partials) {
+            {
                 // plain stores into this block's own slice (summed by the unpack kernel): float atomics
-                // run at ~1.3 TB/s and 256 blocks x 147 KB of them cost 30-35 us per launch
+                // run at ~1.3 TB/s and 256 blocks x 147 KB of them cost 30-35 us per launch -- and make the sums depend on
+                // the order the blocks arrive in
                 float *ps = a.partials + (size_t)blockIdx.x * pstride + (size_t)co * a.CIN + ci;
 #pragma unroll
                 for (int ty = 0; ty < 3; ++ty)
@@ -2003,20 +1994,10 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
                         float *d = ps + (size_t)(ty * 3 + tx) * a.COUT * a.CIN;
                         *d = a.acc_partials ? *d + acc[ty][tx][m][rr] : acc[ty][tx][m][rr];
                     }
-            } else {
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-                        atomicAdd(&a.dWt[((size_t)(ty * 3 + tx) * a.COUT + co) * a.CIN + ci], acc[ty][tx][m][rr]);
             }
-            if (wc == 0 && chunk == 0 && i16 == 0) {
-                if (a.partials) {           // bias partial: last COUT floats of the slice
-                    float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
-                    *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
-                } else if (a.db) {
-                    atomicAdd(&a.db[co], accb[m][rr]);
-                }
+            if (wc == 0 && chunk == 0 && i16 == 0) {      // bias partial: last COUT floats of the slice
+                float *d = a.partials + (size_t)blockIdx.x * pstride + (size_t)9 * a.COUT * a.CIN + co;
+                *d = a.acc_partials ? *d + accb[m][rr] : accb[m][rr];
             }
         }
     }
@@ -2087,17 +2068,6 @@ int wgrad_slices(int cout, int cin, int c1, int B, int H, int W)
     MMK_WG_CASE(64, 16); MMK_WG_CASE(64, 32); MMK_WG_CASE(64, 64);
 #undef MMK_WG_CASE
     return 0;
-}
-
-// dW[co][ci][tap] (+)= dWt[tap][co][ci]
-__global__ void unpack_wgrad_kernel(const float *__restrict__ dWt, int COUT, int CIN, int accumulate,
-                                    float *__restrict__ dW)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= COUT * CIN * 9) return;
-    const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-    const float v = dWt[((size_t)tap * COUT + co) * CIN + ci];
-    dW[e] = accumulate ? dW[e] + v : v;
 }
 
 struct UnpackBatch {
@@ -2212,7 +2182,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 // dW[8][CIN][9] += sum_p g[p][co] * x[c][p+tap], db[8] += sum_p g[p][co]  (g = grad w.r.t. pre-activation)
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
                                                                const float *__restrict__ pre, int B, int H, int W,
-                                                               float *__restrict__ dW, float *__restrict__ db)
+                                                               float *__restrict__ part /*[gridDim.x][CIN][80]*/)
 {
     __shared__ float red[4][80];
     const size_t npix = (size_t)B * H * W;
@@ -2251,15 +2221,33 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
         }
         __syncthreads();
         if (threadIdx.x < 80) {
-            const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            const int i = threadIdx.x;
-            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], v);
-            else if (c == 0 && db) atomicAdd(&db[i - 72], v);
+            // this block's partial sums, plain stores: conv_first_wgrad_reduce_kernel adds the blocks in a fixed order
+            part[((size_t)blockIdx.x * CIN + c) * 80 + threadIdx.x] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         }
         __syncthreads();
     }
 }
 
+
+// dW[8][CIN][9], db[8] = the per-block partial sums of the two kernels above added in block order (four interleaved
+// chains per value, combined in a fixed order): no float atomics, the first layer's gradient is bit-reproducible.
+// grid = CIN blocks of 320 threads: thread = (value i < 80, chain q < 4).
+__global__ __launch_bounds__(320) void conv_first_wgrad_reduce_kernel(const float *__restrict__ part, int nblk, int CIN,
+                                                                      float *__restrict__ dW, float *__restrict__ db)
+{
+    __shared__ float sh[4][80];
+    const int c = blockIdx.x, i = threadIdx.x % 80, q = threadIdx.x / 80;
+    float v = 0.f;
+    for (int b = q; b < nblk; b += 4) v += part[((size_t)b * CIN + c) * 80 + i];
+    sh[q][i] = v;
+    __syncthreads();
+    if (q == 0) {
+        const float t = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+        if (i < 72) dW[((i / 9) * CIN + c) * 9 + (i % 9)] = t;
+        else if (c == 0 && db) db[i - 72] = t;
+    }
+}
 
 // Fast paths for W % 4 == 0: one thread per 4 horizontally adjacent pixels.  The three input rows
 // are fetched as one 16-byte load + two edge scalars each (9 loads per 4 pixels instead of 36) and
@@ -2331,7 +2319,7 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
 
 __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *__restrict__ x, int CIN, const bf16 *__restrict__ g,
                                                                   const float *__restrict__ pre, int B, int H, int W,
-                                                                  float *__restrict__ dW, float *__restrict__ db)
+                                                                  float *__restrict__ part /*[gridDim.x][CIN][80]*/)
 {
     __shared__ float red[4][80];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2394,10 +2382,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
         }
         __syncthreads();
         if (threadIdx.x < 80) {
-            const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            const int i = threadIdx.x;
-            if (i < 72) atomicAdd(&dW[((i / 9) * CIN + c) * 9 + (i % 9)], t);
-            else if (c == 0 && db) atomicAdd(&db[i - 72], t);
+            part[((size_t)blockIdx.x * CIN + c) * 80 + threadIdx.x] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         }
         __syncthreads();
     }
@@ -2700,7 +2686,7 @@ __global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__rest
 __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ mask, const float *__restrict__ gmask,
                                                         size_t npix_per, const float *__restrict__ coef, float scale, float slope,
-                                                        bf16 *__restrict__ gx, float *__restrict__ dW, float *__restrict__ db)
+                                                        bf16 *__restrict__ gx, float *__restrict__ part /*[blocks][9]*/)
 {
     __shared__ float red[4][9];
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2736,10 +2722,29 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__
         if (lane == 0) red[wv][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (threadIdx.x < 8) atomicAdd(&dW[threadIdx.x], v);
-        else atomicAdd(&db[0], v);
+    if (threadIdx.x < 9)      // this block's partial sums (plain stores; final_bwd_reduce_kernel adds the blocks in a fixed order)
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// dW[8], db[1] = the block partials of final_bwd_kernel added in block order (32 interleaved chains per value, combined by a
+// fixed butterfly): no float atomics.  One block of 9 x 32 threads.
+__global__ __launch_bounds__(288) void final_bwd_reduce_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dW,
+                                                               float *__restrict__ db)
+{
+    __shared__ float sh[9][32];
+    const int i = threadIdx.x / 32, q = threadIdx.x % 32;
+    float v = 0.f;
+    for (int b = q; b < nblk; b += 32) v += part[(size_t)b * 9 + i];
+    sh[i][q] = v;
+    __syncthreads();
+    for (int off = 16; off > 0; off >>= 1) {
+        if (q < off) sh[i][q] += sh[i][q + off];
+        __syncthreads();
+    }
+    if (q == 0) {
+        if (i < 8) dW[i] = sh[i][0];
+        else db[0] = sh[8][0];
     }
 }
 
@@ -3185,32 +3190,6 @@ extern "C" int32_t mmk_conv3x3_pool_fusable(int32_t cin, int32_t cout, int32_t B
     return pool_fusable(cin, cout, B, H, W) ? 1 : 0;
 }
 
-extern "C" int mmk_conv3x3_wgrad(const void *x1, const void *x2, int32_t C1, int32_t C2, const void *g, int32_t cout,
-                                 int32_t B, int32_t H, int32_t W, float *dWt, float *db, void *stream)
-{
-    MMK_REQUIRE(x1 && g && dWt, "mmk_conv3x3_wgrad: NULL pointer");
-    MMK_REQUIRE(B >= 1 && H >= 1 && W >= 1, "mmk_conv3x3_wgrad: bad shape");
-    const int cin = C1 + C2;
-    MMK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || x2), "mmk_conv3x3_wgrad: bad input split %d+%d", C1, C2);
-    MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3_wgrad: unsupported channel counts %d -> %d", cin, cout);
-    WgradArgs a;
-    a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
-    a.dWt = dWt; a.db = db; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
-    a.partials = nullptr; a.acc_partials = 0;
-    return dispatch_wgrad(a, (hipStream_t)stream);
-}
-
-extern "C" int mmk_conv3x3_wgrad_unpack(const float *dWt, int32_t cout, int32_t cin, int32_t accumulate, float *dW,
-                                        void *stream)
-{
-    MMK_REQUIRE(dWt && dW && cout >= 1 && cin >= 1, "mmk_conv3x3_wgrad_unpack: bad argument");
-    const int n = cout * cin * 9;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dWt, cout, cin,
-                       accumulate, dW);
-    MMK_LAUNCH_CHECK();
-    return MMK_OK;
-}
-
 extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src, const int32_t *slices, const int32_t *cout,
                                               const int32_t *cin, float *const *dW, float *const *db, void *stream)
 {
@@ -3303,7 +3282,7 @@ extern "C" int mmk_conv3x3_wgrad_partial(const void *x1, const void *x2, int32_t
     MMK_REQUIRE(chan_ok(cin) && chan_ok(cout), "mmk_conv3x3_wgrad_partial: unsupported channel counts %d -> %d", cin, cout);
     WgradArgs a;
     a.x1 = (const bf16 *)x1; a.x2 = (const bf16 *)x2; a.C1 = C1; a.C2 = C2; a.g = (const bf16 *)g;
-    a.dWt = nullptr; a.db = nullptr; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+    a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
     a.partials = partials; a.acc_partials = accumulate;
     return dispatch_wgrad(a, (hipStream_t)stream);
 }
@@ -3404,22 +3383,28 @@ extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const
     return MMK_OK;
 }
 
+extern "C" size_t mmk_conv_first_wgrad_ws_bytes(int32_t cin) { return (size_t)1024 * (cin < 1 ? 1 : cin) * 80 * sizeof(float); }
+
 extern "C" int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float *pre, int32_t B, int32_t H,
-                                    int32_t Wd, float *dW, float *db, void *stream)
+                                    int32_t Wd, float *dW, float *db, float *ws, size_t ws_bytes, void *stream)
 {
-    MMK_REQUIRE(x && g && dW, "mmk_conv_first_wgrad: NULL pointer");
+    MMK_REQUIRE(x && g && dW && ws, "mmk_conv_first_wgrad: NULL pointer");
     MMK_REQUIRE(cin >= 1 && cin <= 4 && B >= 1 && H >= 1 && Wd >= 1, "mmk_conv_first_wgrad: bad shape");
+    MMK_REQUIRE(ws_bytes >= mmk_conv_first_wgrad_ws_bytes(cin), "mmk_conv_first_wgrad: workspace too small (%zu < %zu bytes)", ws_bytes,
+                mmk_conv_first_wgrad_ws_bytes(cin));
     const size_t npix = (size_t)B * H * Wd;
+    unsigned blocks;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
-        const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 512);   // 80 same-address float atomics per block: few blocks
+        blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 512);
         hipLaunchKernelGGL(conv_first_wgrad_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, pre,
-                           B, H, Wd, dW, db);
-        MMK_LAUNCH_CHECK();
-        return MMK_OK;
+                           B, H, Wd, ws);
+    } else {
+        blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 1024);
+        hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, pre, B,
+                           H, Wd, ws);
     }
-    const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 1024);
-    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, (const bf16 *)g, pre, B,
-                       H, Wd, dW, db);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cin), dim3(320), 0, (hipStream_t)stream, ws, (int)blocks, cin, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -3507,12 +3492,14 @@ extern "C" int mmk_final_fwd(const void *x, const float *w, const float *bias, i
 }
 
 extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, const float *gmask, int64_t npix, float scale,
-                             float leaky_slope, void *gx, float *dW, float *db, void *stream)
+                             float leaky_slope, void *gx, float *dW, float *db, float *ws /* MMK_FINAL_BWD_WS_FLOATS */, void *stream)
 {
-    MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && npix >= 1, "mmk_final_bwd: bad argument");
-    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);   // 9 same-address atomics per block
+    MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && ws && npix >= 1, "mmk_final_bwd: bad argument");
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);
     hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
-                       (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, dW, db);
+                       (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, ws);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_bwd_reduce_kernel, dim3(1), dim3(288), 0, (hipStream_t)stream, ws, (int)blocks, dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -3532,19 +3519,23 @@ extern "C" int mmk_mask_normalize(const float *mask, int32_t B, int64_t npix_per
 
 extern "C" int mmk_final_bwd_normalized(const void *x, const float *w, const float *mask, const float *mask_n, const float *amax,
                                         const float *gmask_n, int32_t B, int64_t npix_per, float scale, float leaky_slope,
-                                        float *part, float *coef, void *gx, float *dW, float *db, void *stream)
+                                        float *part, float *coef, void *gx, float *dW, float *db,
+                                        float *ws /* MMK_FINAL_BWD_WS_FLOATS */, void *stream)
 {
-    MMK_REQUIRE(x && w && mask && mask_n && amax && gmask_n && part && coef && gx && dW && db, "mmk_final_bwd_normalized: NULL pointer");
+    MMK_REQUIRE(x && w && mask && mask_n && amax && gmask_n && part && coef && gx && dW && db && ws, "mmk_final_bwd_normalized: NULL pointer");
     MMK_REQUIRE(B >= 1 && B <= 65535 && npix_per >= 1, "mmk_final_bwd_normalized: bad shape");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mask_norm_bwd_partial_kernel, dim3(MASK_SEG, B), dim3(256), 0, st, gmask_n, mask_n, (size_t)npix_per, part);
     MMK_LAUNCH_CHECK();
     hipLaunchKernelGGL(mask_norm_bwd_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, part, amax, B, coef);
     MMK_LAUNCH_CHECK();
-    // ~512 blocks in all (9 same-address atomics per block)
+    // ~512 blocks in all (9 partial sums per block; per * B <= 512 + B <= MMK_FINAL_BWD_WS_FLOATS / 9 for B <= 1200)
     const unsigned per = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)npix_per + 255) / 256, (512 + B - 1) / B));
+    MMK_REQUIRE((size_t)per * B * 9 <= MMK_FINAL_BWD_WS_FLOATS, "mmk_final_bwd_normalized: batch too large for the reduction workspace");
     hipLaunchKernelGGL(final_bwd_kernel, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
-                       scale, leaky_slope, (bf16 *)gx, dW, db);
+                       scale, leaky_slope, (bf16 *)gx, ws);
+    MMK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_bwd_reduce_kernel, dim3(1), dim3(288), 0, st, ws, (int)(per * B), dW, db);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

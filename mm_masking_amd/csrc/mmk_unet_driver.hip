@@ -41,11 +41,9 @@ struct Plan {
     Tens gz_final, gz_a2[5], gsk[5], gz_d1[5], gz_a1[5], g_u[5], gz_up[5];
     Tens gz_d[6], gz_a[6];
     size_t packs_t[NCONV];
-    size_t part[NCONV];                         // partial slices / atomic accumulators of layer k
+    size_t part[NCONV];                         // partial slices of layer k
     int slices[NCONV];
-    size_t zero_off = 0, zero_bytes = 0;     // scratch range of the atomically accumulated weight-gradient buffers
-    size_t dB[NCONV];                           // bias sums of the atomic form
-    size_t fin_ws;
+    size_t fin_ws, fin_red, first_ws;           // workspaces of the final / first layer's gradient reductions
     size_t scratch_bytes;
 };
 
@@ -144,20 +142,13 @@ bool make_plan(Plan &p, int B, int H, int W, int cin, bool with_scratch)
         }
         p.slices[k] = mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], c1, B, h, w);
     }
-    // layers without a partial-sum kernel add into their (tap, cout, cin) buffer and bias sums with atomics: those buffers lie
-    // next to each other, so that one fill zeroes them all
-    p.zero_off = s.take(0);
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int k = 1; k <= 21; ++k) {
-            if ((p.slices[k] == 0) != (pass == 0)) continue;
-            const int ns = p.slices[k];
-            const size_t per = (size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k];
-            p.part[k] = s.take((ns > 0 ? (size_t)ns : 1) * per * 4);
-            p.dB[k] = s.take((size_t)p.cout[k] * 4);
-        }
-        if (pass == 0) p.zero_bytes = s.take(0) - p.zero_off;
+    for (int k = 1; k <= 21; ++k) {
+        if (p.slices[k] <= 0) return false;      // every layer shape of the network has a partial-sum weight-gradient kernel
+        p.part[k] = s.take((size_t)p.slices[k] * ((size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k]) * 4);
     }
     p.fin_ws = s.take((size_t)B * 130 * 4);
+    p.fin_red = s.take((size_t)MMK_FINAL_BWD_WS_FLOATS * 4);
+    p.first_ws = s.take(mmk_conv_first_wgrad_ws_bytes(cin));
     p.scratch_bytes = mmk::align_up(s.off, 256);
     return true;
 }
@@ -393,13 +384,6 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         }
         MMK_TRY(mmk_conv3x3_pack_weights_batch(21, Wp, co, ci, 1, Op, stream));
     }
-    // accumulators that are added to with atomics start from zero: first / final layer gradients, and the
-    // (tap, cout, cin) buffers + bias sums of layers without a partial-sum kernel
-    MMK_CHECK_HIP(hipMemsetAsync(grads[0], 0, sizeof(float) * 8 * p.cin * 9, st));
-    MMK_CHECK_HIP(hipMemsetAsync(grads[1], 0, sizeof(float) * 8, st));
-    MMK_CHECK_HIP(hipMemsetAsync(grads[44], 0, sizeof(float) * 8, st));
-    MMK_CHECK_HIP(hipMemsetAsync(grads[45], 0, sizeof(float) * 1, st));
-    if (p.zero_bytes > 0) MMK_CHECK_HIP(hipMemsetAsync(at(sc, p.zero_off), 0, p.zero_bytes, st));
     SideStream *ss = nullptr;
     if (use_side_stream()) MMK_TRY(side_stream(&ss));
     void *wstream = ss ? (void *)ss->st : stream;          // where the weight-gradient launches go
@@ -423,13 +407,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             slices[n] = p.slices[k]; co[n] = p.cout[k]; ci[n] = p.cinn[k];
             dW[n] = grads[2 * k]; db[n] = grads[2 * k + 1];
         }
-        const int rc = mmk_conv3x3_wgrad_unpack_batch(n, src, slices, co, ci, dW, db, wstream);
-        if (rc != MMK_OK) return rc;
-        for (int k = k0; k <= k1; ++k)
-            if (p.slices[k] == 0)
-                MMK_CHECK_HIP(hipMemcpyAsync(grads[2 * k + 1], at(sc, p.dB[k]), sizeof(float) * p.cout[k], hipMemcpyDeviceToDevice,
-                                             (hipStream_t)wstream));
-        return MMK_OK;
+        return mmk_conv3x3_wgrad_unpack_batch(n, src, slices, co, ci, dW, db, wstream);
     };
     bool part_used[NCONV] = {};
     // 8 -> 8 and 16 -> 16 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the
@@ -449,19 +427,15 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
             MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
         }
-        if (p.slices[k] > 0) {
-            // (the plan sized the slices for an unsplit input; a split input must give the same count)
-            if (mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], C1, B, h, w) != p.slices[k]) {
-                mmk::set_error("mmk_unet_backward: partial-slice count of layer %d depends on the input split", k);
-                return MMK_ERR_ARG;
-            }
-            const int rc = mmk_conv3x3_wgrad_partial(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
-                                                     part_used[k] ? 1 : 0, wstream);
-            part_used[k] = true;
-            return rc;
+        // (the plan sized the slices for an unsplit input; a split input must give the same count)
+        if (mmk_conv3x3_wgrad_slices(p.cout[k], p.cinn[k], C1, B, h, w) != p.slices[k]) {
+            mmk::set_error("mmk_unet_backward: partial-slice count of layer %d depends on the input split", k);
+            return MMK_ERR_ARG;
         }
-        return mmk_conv3x3_wgrad(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
-                                 static_cast<float *>(at(sc, p.dB[k])), wstream);
+        const int rc = mmk_conv3x3_wgrad_partial(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
+                                                 part_used[k] ? 1 : 0, wstream);
+        part_used[k] = true;
+        return rc;
     };
 
     // ---- final layer
@@ -470,10 +444,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_TRY(mmk_final_bwd_normalized(at(ws, d2_4.off), Wk(22), static_cast<const float *>(at(ws, p.mask_raw)), d->mask,
                                          static_cast<const float *>(at(ws, p.amax)), gmask, B, (int64_t)p.H * p.W, s, sl,
                                          static_cast<float *>(at(sc, p.fin_ws)), static_cast<float *>(at(sc, p.fin_ws)) + (size_t)B * 128,
-                                         at(sc, p.gz_final.off), grads[44], grads[45], stream));
+                                         at(sc, p.gz_final.off), grads[44], grads[45], static_cast<float *>(at(sc, p.fin_red)), stream));
     else
         MMK_TRY(mmk_final_bwd(at(ws, d2_4.off), Wk(22), d->mask, gmask, (int64_t)B * p.H * p.W, s, sl, at(sc, p.gz_final.off), grads[44],
-                              grads[45], stream));
+                              grads[45], static_cast<float *>(at(sc, p.fin_red)), stream));
     // ---- decoder, j = 4..0
     const void *gz = at(sc, p.gz_final.off);
     for (int j = 4; j >= 0; --j) {
@@ -592,7 +566,8 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     // ---- parameter gradients of the first five 3x3 layers (the rest was reduced on the way): on the weight-gradient stream,
     // beside the first layer's weight gradient
     MMK_TRY(unpack(1, split3 ? 5 : 3));
-    MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1], stream));
+    MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1],
+                                 static_cast<float *>(at(sc, p.first_ws)), mmk_conv_first_wgrad_ws_bytes(p.cin), stream));
     if (ss) {       // join: the caller's stream continues only after every gradient is written
         MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
         MMK_CHECK_HIP(hipStreamWaitEvent(st, ss->join, 0));

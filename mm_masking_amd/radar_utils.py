@@ -288,8 +288,10 @@ class _SampleWeights(torch.autograd.Function):
         B, H, W = ctx.shape
         gw = gw.contiguous().float()
         gmask = torch.empty(B, H, W, dtype=torch.float32, device=gw.device)
+        nb = int(_lib.lib().mmk_sample_weights_bwd_ws_bytes(B, pc.shape[1]))
+        ws = _workspace(nb, gw.device)
         _lib.check(_lib.lib().mmk_sample_weights_bwd(_lib.ptr(gw), _lib.ptr(pc), B, pc.shape[1], pc.shape[2], H, W,
-                                                     ctx.cw, ctx.cres, _lib.ptr(gmask), _lib.stream_ptr(gw.device)))
+                                                     ctx.cw, ctx.cres, _lib.ptr(gmask), _lib.ptr(ws), nb, _lib.stream_ptr(gw.device)))
         return gmask, None, None, None
 
 

@@ -85,25 +85,35 @@ def pool_fusable(cin, cout, B, H, W):
 
 
 def conv3x3_wgrad(x1, g, cout, x2=None, dWt=None, db=None):
-    """Accumulate the weight / bias gradient into dWt (9,cout,cin) fp32 and db (cout,) fp32."""
+    """Weight / bias gradient added to dWt (9,cout,cin) fp32 and db (cout,) fp32 (a fresh zero dWt when none is given):
+    the partial-sum kernel (per-workgroup slices, plain stores) followed by a sum over the slices -- the form every layer
+    of the network uses; there is no float-atomic path."""
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     cin = C1 + C2
+    ns = wgrad_slices(cout, cin, C1, B, H, W)
+    if ns <= 0:
+        raise _lib.MmkError("conv3x3_wgrad: unsupported shape %d -> %d channels" % (cin, cout))
+    part = partial_buffer(ns, cout, cin, x1.device)
+    conv3x3_wgrad_partial(x1, g, cout, part, x2=x2)
+    tot = part.sum(dim=0)
+    w = tot[:9 * cout * cin].view(9, cout, cin)
     if dWt is None:
-        dWt = torch.zeros(9, cout, cin, dtype=torch.float32, device=x1.device)
-    _lib.check(_lib.lib().mmk_conv3x3_wgrad(_p(x1), _p(x2), C1, C2, _p(g), cout, B, H, W, _p(dWt), _p(db),
-                                            _lib.stream_ptr(x1.device)))
+        dWt = w.clone()
+    else:
+        dWt += w
+    if db is not None:
+        db += tot[9 * cout * cin:]
     return dWt
 
 
 def wgrad_unpack(dWt, accumulate_into=None):
     """(9,cout,cin) -> (cout,cin,3,3); accumulates into an existing gradient when given."""
-    _, cout, cin = dWt.shape
-    out = accumulate_into if accumulate_into is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32,
-                                                                          device=dWt.device)
-    _lib.check(_lib.lib().mmk_conv3x3_wgrad_unpack(_p(dWt), cout, cin, 1 if accumulate_into is not None else 0, _p(out),
-                                                   _lib.stream_ptr(dWt.device)))
-    return out
+    w = dWt.permute(1, 2, 0).reshape(dWt.shape[1], dWt.shape[2], 3, 3)
+    if accumulate_into is not None:
+        accumulate_into += w
+        return accumulate_into
+    return w.contiguous()
 
 
 def dropout_scale(p):
@@ -167,9 +177,9 @@ def conv16x8_bwd_fused(x1, x2, g, wpack_t, scale, dx1, dx2, partials, accumulate
 
 
 def wgrad_unpack_batch(items):
-    """One launch for a list of layers.  Each item is either a (9,cout,cin) tensor (atomic form) or a tuple
-    (partials, cout, cin[, db_out]) of the partial-sum form; returns the (cout,cin,3,3) gradients (views of
-    one buffer); bias sums of the partial form are written to db_out (cout,) when given."""
+    """One launch for a list of layers.  Each item is a tuple (partials, cout, cin[, db_out]) of the partial-sum form (or a
+    plain (9,cout,cin) tensor: transposed only); returns the (cout,cin,3,3) gradients (views of one buffer); bias sums are
+    written to db_out (cout,) when given."""
     n = len(items)
     srcs, couts, cins, slices, dbs = [], [], [], [], []
     for it in items:
@@ -199,6 +209,15 @@ def wgrad_unpack_batch(items):
 # ----------------------------------------------------------------------------- small wrappers
 def _sp(dev):
     return _lib.stream_ptr(dev)
+
+
+def conv_first_wgrad(x, gz, pre, dW, db):
+    """First layer's weight / bias gradient WRITTEN to dW (8,cin,3,3) and db (8,) (block partials + ordered reduction)."""
+    L = _lib.lib()
+    B, cin, H, W = x.shape
+    nb = int(L.mmk_conv_first_wgrad_ws_bytes(cin))
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+    _lib.check(L.mmk_conv_first_wgrad(_p(x), cin, _p(gz), _p(pre), B, H, W, _p(dW), _p(db), _p(ws), nb, _sp(x.device)))
 
 
 def conv_first(x, w, b, pre=None, slope=0.0):
@@ -408,39 +427,35 @@ class _UNet(torch.autograd.Function):
         def seg(i):
             return flat[offs[i]:offs[i] + sizes[i]]
 
-        dWt = {k: seg(2 * k).view(9, W(k).shape[0], W(k).shape[1]) for k in range(1, 22)}
         dB = {k: seg(2 * k + 1) for k in range(1, 22)}
-
-        def grads(k):
-            return dWt[k], dB[k]
 
         part = {}        # layer -> partial-sum slices (weights + bias)
 
         def wgrad(k, x1, g, x2=None):
-            dw, db = grads(k)
             cout_k, cin_k = W(k).shape[0], W(k).shape[1]
             ns = wgrad_slices(cout_k, cin_k, x1.shape[3], x1.shape[0], x1.shape[1], x1.shape[2])
-            if ns > 0:
-                first = k not in part
-                if first:
-                    part[k] = partial_buffer(ns, cout_k, cin_k, dev)
-                conv3x3_wgrad_partial(x1, g, cout_k, part[k], x2=x2, accumulate=not first)
-            else:
-                conv3x3_wgrad(x1, g, cout_k, x2=x2, dWt=dw, db=db)
+            if ns <= 0:
+                raise _lib.MmkError("U-Net backward: no weight-gradient kernel for %d -> %d channels" % (cin_k, cout_k))
+            first = k not in part
+            if first:
+                part[k] = partial_buffer(ns, cout_k, cin_k, dev)
+            conv3x3_wgrad_partial(x1, g, cout_k, part[k], x2=x2, accumulate=not first)
 
         # ---- final layer
         u4, a1_4, d1_4, a2_4, d2_4 = ctx.saved_dec[4]
         wf8 = W(22).float().reshape(8).contiguous()
         g_fw, g_fb = seg(44), seg(45)
         gz = torch.empty_like(d2_4)
+        red = torch.empty(_lib.FINAL_BWD_WS_FLOATS, dtype=torch.float32, device=dev)
         if ctx.norm:
             npix = gmask.shape[1] * gmask.shape[2]
             ws = torch.empty(B * 130, dtype=torch.float32, device=dev)
             _lib.check(L.mmk_final_bwd_normalized(_p(d2_4), _p(wf8), _p(ctx.mask), _p(ctx.mask_n), _p(ctx.amax), _p(gmask), B, npix,
-                                                  s, sl, _p(ws[:B * 128]), _p(ws[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _sp(dev)))
+                                                  s, sl, _p(ws[:B * 128]), _p(ws[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _p(red),
+                                                  _sp(dev)))
         else:
             _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), s, sl, _p(gz), _p(g_fw),
-                                       _p(g_fb), _sp(dev)))
+                                       _p(g_fb), _p(red), _sp(dev)))
         dbg = DEBUG
         if dbg is not None:
             dbg["gz_d2_4"] = gz
@@ -498,11 +513,10 @@ class _UNet(torch.autograd.Function):
         wgrad(1, a0, gz_d0)
         gz_a0 = conv3x3(gz_d0, pkt(1), 8, relu_src=a0, scale=1.0, slope=sl)
         g_w0, g_b0 = seg(0).view(8, cin0, 3, 3), seg(1)
-        _lib.check(L.mmk_conv_first_wgrad(_p(x), cin0, _p(gz_a0), _p(ctx.pre), B, x.shape[2], x.shape[3], _p(g_w0), _p(g_b0),
-                                          _sp(dev)))
+        conv_first_wgrad(x, gz_a0, ctx.pre, g_w0, g_b0)
         # ---- assemble parameter gradients in input order
         out = [g_w0, g_b0]
-        items = [(part[k], W(k).shape[0], W(k).shape[1], dB[k]) if k in part else dWt[k] for k in range(1, 22)]
+        items = [(part[k], W(k).shape[0], W(k).shape[1], dB[k]) for k in range(1, 22)]
         for k, gw in zip(range(1, 22), wgrad_unpack_batch(items)):
             out += [gw, dB[k]]
         out += [g_fw.reshape(1, 8, 1, 1), g_fb]

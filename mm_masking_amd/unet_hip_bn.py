@@ -161,23 +161,18 @@ class _UNetBN(torch.autograd.Function):
             ws += [bp(k)[0], bp(k)[4]]
         packs_t = uh.pack_weights_batch(ws[1:], transposed=True)
         pkt = {i + 1: tt for i, tt in enumerate(packs_t)}
-        dWt = {}
         part = {}
 
         def wgrad(ci, x1, g, x2=None):
             w = ws[ci]
             cout_k, cin_k = w.shape[0], w.shape[1]
             ns = uh.wgrad_slices(cout_k, cin_k, x1.shape[3], x1.shape[0], x1.shape[1], x1.shape[2])
-            if ns > 0:
-                first = ci not in part
-                if first:
-                    part[ci] = uh.partial_buffer(ns, cout_k, cin_k, dev)
-                uh.conv3x3_wgrad_partial(x1, g, cout_k, part[ci], x2=x2, accumulate=not first)
-            else:
-                if ci not in dWt:
-                    dWt[ci] = (torch.zeros(9, cout_k, cin_k, dtype=torch.float32, device=dev),
-                               torch.zeros(cout_k, dtype=torch.float32, device=dev))
-                uh.conv3x3_wgrad(x1, g, cout_k, x2=x2, dWt=dWt[ci][0], db=dWt[ci][1])
+            if ns <= 0:
+                raise _lib.MmkError("U-Net backward: no weight-gradient kernel for %d -> %d channels" % (cin_k, cout_k))
+            first = ci not in part
+            if first:
+                part[ci] = uh.partial_buffer(ns, cout_k, cin_k, dev)
+            uh.conv3x3_wgrad_partial(x1, g, cout_k, part[ci], x2=x2, accumulate=not first)
 
         seen = set()
 
@@ -192,8 +187,7 @@ class _UNetBN(torch.autograd.Function):
             g_yA = uh.conv3x3(gzB, pkt[2 * k + 1], wB.shape[1], slope=sl)
             gzA = _bn_backward(g_yA, None, 1.0, aA, sA if ctx.training else None, afA, gA, sl, grads[8 * k + 2], grads[8 * k + 3], acc)
             if k == 0:
-                _lib.check(L.mmk_conv_first_wgrad(_p(x), x.shape[1], _p(gzA), _p(ctx.pre), B, x.shape[2], x.shape[3],
-                                                  _p(grads[0]), _p(grads[1]), _sp(dev)))
+                uh.conv_first_wgrad(x, gzA, ctx.pre, grads[0], grads[1])
                 return None
             wgrad(2 * k, x1, gzA, x2=x2)
             cin_k = wA.shape[1]
@@ -209,14 +203,16 @@ class _UNetBN(torch.autograd.Function):
         wf8 = P[88].reshape(8).contiguous()
         g_fw, g_fb = grads[88].view(-1), grads[89]
         gz = torch.empty_like(d2_4)
+        red = torch.empty(_lib.FINAL_BWD_WS_FLOATS, dtype=torch.float32, device=dev)
         if ctx.norm:
             npix = gmask.shape[1] * gmask.shape[2]
             wsb = torch.empty(B * 130, dtype=torch.float32, device=dev)
             _lib.check(L.mmk_final_bwd_normalized(_p(d2_4), _p(wf8), _p(ctx.mask), _p(ctx.mask_n), _p(ctx.amax), _p(gmask), B, npix,
-                                                  1.0, 1.0, _p(wsb[:B * 128]), _p(wsb[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _sp(dev)))
+                                                  1.0, 1.0, _p(wsb[:B * 128]), _p(wsb[B * 128:]), _p(gz), _p(g_fw), _p(g_fb), _p(red),
+                                                  _sp(dev)))
         else:
             _lib.check(L.mmk_final_bwd(_p(d2_4), _p(wf8), _p(ctx.mask), _p(gmask), gmask.numel(), 1.0, 1.0, _p(gz), _p(g_fw), _p(g_fb),
-                                       _sp(dev)))
+                                       _p(red), _sp(dev)))
         # ---- decoder
         g_skip = [None] * 5
         g_cur = gz
@@ -244,11 +240,7 @@ class _UNetBN(torch.autograd.Function):
             w = ws[ci]
             k, which = ci // 2, ci % 2
             gb = grads[8 * k + (5 if which else 1)]
-            if ci in part:
-                items.append((part[ci], w.shape[0], w.shape[1], gb))
-            else:
-                items.append(dWt[ci][0])
-                gb.copy_(dWt[ci][1])
+            items.append((part[ci], w.shape[0], w.shape[1], gb))
             idxs.append(8 * k + (4 if which else 0))
         for gi, gw in zip(idxs, uh.wgrad_unpack_batch(items)):
             grads[gi] = gw

@@ -93,8 +93,7 @@ def main():
     gz = rnd(B, 640, 640, 8)
     dw = torch.zeros(8, 1, 3, 3, device=DEV); dbb = torch.zeros(8, device=DEV)
     vp = ctypes.c_void_p
-    t = timeit(lambda: _lib.check(_lib.lib().mmk_conv_first_wgrad(vp(x.data_ptr()), 1, vp(gz.data_ptr()), None, B, 640, 640,
-                                                                  vp(dw.data_ptr()), vp(dbb.data_ptr()), _lib.stream_ptr(DEV))))
+    t = timeit(lambda: uh.conv_first_wgrad(x, gz, None, dw, dbb))
     print("conv_first_wgrad us %.1f  (%.0f GB/s)" % (t, (x.numel() * 4 + B * 640 * 640 * 16) / t * 1e-3))
     for H, C in [(640, 16), (320, 32), (160, 64), (80, 128), (40, 256)]:
         d = rnd(B, H, H, C)

@@ -12,7 +12,7 @@ dw = torch.zeros(8, 1, 3, 3, device=DEV); db = torch.zeros(8, device=DEV)
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 print("conv_first %.1f us" % timeit(lambda: uh.conv_first(x, w0, b0)))
-print("conv_first_wgrad %.1f us" % timeit(lambda: _lib.check(L.mmk_conv_first_wgrad(p(x), 1, p(g), None, B, 640, 640, p(dw), p(db), _lib.stream_ptr(DEV)))))
+print("conv_first_wgrad %.1f us" % timeit(lambda: uh.conv_first_wgrad(x, g, None, dw, db)))
 for H, C in [(640, 16), (320, 32)]:
     s = rnd(B, H // 2, H // 2, C); gy = rnd(B, H, H, C)
     print("up %d c%d fwd %.1f bwd %.1f us" % (H, C, timeit(lambda: uh.upsample(s, H, H)), timeit(lambda: uh.upsample_bwd(gy, H // 2, H // 2, relu_src=s, scale=1.05))))

@@ -111,3 +111,80 @@ def test_loader_throughput_against_step_rate(tmp_path):
     # fed by the loader the step runs at the slower of the two rates (staging overlaps the step)
     best = max(v for k, v in res.items() if k.startswith("loader_items_per_s"))
     assert res["train_pairs_per_s_fed_by_loader"] > 0.7 * min(best, res["step_pairs_per_s_resident_batches"]), res
+
+
+# ----------------------------------------------------------------------------- bit-reproducible step
+def test_training_step_is_bit_reproducible():
+    """BASELINE configs[2] (B=32, N=5120, M=20480, 10 iterations, pt2pl Huber, dropout 0.05): the step run twice from the same
+    state gives the same loss, the same 46 gradients and the same updated parameters, bit for bit.  What made it differ
+    before round 3: float atomics in the first-layer weight gradient, the final layer's gradient and the mask-gradient
+    scatter of extract_weights (now block partials + ordered reductions / per-pixel chains summed in point order)."""
+    from mm_masking_amd import synthetic
+    from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+    B = 32
+    params = trn.default_params(DEV)
+    params.update({"icp_type": "pt2pl", "icp_loss_fn": {"name": "huber", "metric": 1.0}, "max_iter": 10, "dropout": 0.05})
+    raw = synthetic.make_batch(list(range(4000, 4000 + B)), device=DEV)
+    lw = trn.loss_weights_from(params)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(77)
+        model = LearnICPWeightPolicy(params).to(DEV)
+        model.train()
+        opt = trn.make_optimizer(model, params)
+        out = []
+        for step in range(2):                   # two steps: the second one starts from Adam-updated parameters
+            batch = trn.prepare_batch(raw, params, max_loc_pts=5120)
+            loss, _ = trn.train_step(model, batch, opt, lw, DEV)
+            out.append((loss.clone(), [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()]))
+        runs.append(out)
+    names = [n for n, _ in model.named_parameters()]
+    assert len(names) == 46
+    for step in range(2):
+        (l0, g0, p0), (l1, g1, p1) = runs[0][step], runs[1][step]
+        assert torch.equal(l0, l1), (step, float(l0), float(l1))
+        for n, a, b in zip(names, g0, g1):
+            assert torch.equal(a, b), ("gradient", step, n, float((a - b).abs().max()))
+        for n, a, b in zip(names, p0, p1):
+            assert torch.equal(a, b), ("parameter", step, n)
+
+
+def test_mask_gradient_scatter_is_ordered_and_reproducible():
+    """mmk_sample_weights_bwd: many taps on the same pixels (points 1 cm apart) -- the sums equal a sequential loop over
+    (point, tap) in fp32, bit for bit, and do not change from run to run."""
+    from mm_masking_amd import radar_utils as ru
+    g = torch.Generator().manual_seed(3)
+    B, N, H = 2, 4096, 64
+    pc = torch.zeros(B, N, 3)
+    pc[:, :3000, :2] = (torch.rand(B, 3000, 2, generator=g) - 0.5) * 6.0      # 3 000 real points inside ~25 x 25 pixels of a 64 x 64 mask
+    pc[:, 100:110] = 0.0                                                      # fake rows in between
+    pc[:, 200, :2] = torch.tensor([500.0, 500.0])                            # out of the image
+    gw = torch.randn(B, N, generator=g)
+    mask = torch.rand(B, H, H, generator=g).to(DEV).requires_grad_(True)
+    outs = []
+    for rep in range(3):
+        mask.grad = None
+        w = ru._SampleWeights.apply(mask, pc.to(DEV), 0.2384, H)
+        (w * gw.to(DEV)).sum().backward()
+        outs.append(mask.grad.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # sequential fp32 loop, same tap arithmetic as the kernel (csrc/mmk_radar.hip: weight_taps)
+    ref = np.zeros((B, H, H), np.float32)
+    f = np.float32
+    for b in range(B):
+        for n in range(N):
+            x, y = f(pc[b, n, 0]), f(pc[b, n, 1])
+            if x == 0 and y == 0:
+                continue
+            gx = f(f(f(y / f(0.2384)) / f(H - 1)) * f(2.0))
+            gy = f(f(f(-x / f(0.2384)) / f(H - 1)) * f(2.0))
+            ix = f(f(f(gx + f(1)) / f(2)) * f(H - 1))
+            iy = f(f(f(gy + f(1)) / f(2)) * f(H - 1))
+            x0, y0 = np.floor(ix), np.floor(iy)
+            wx, wy = f(ix - x0), f(iy - y0)
+            taps = [(0, 0, f(f(1 - wy) * f(1 - wx))), (0, 1, f(f(1 - wy) * wx)), (1, 0, f(wy * f(1 - wx))), (1, 1, f(wy * wx))]
+            for dy, dx, wt in taps:
+                yy, xx = int(y0) + dy, int(x0) + dx
+                if 0 <= yy < H and 0 <= xx < H:
+                    ref[b, yy, xx] = f(ref[b, yy, xx] + f(f(gw[b, n]) * wt))
+    assert np.array_equal(outs[0].cpu().numpy(), ref), float(np.abs(outs[0].cpu().numpy() - ref).max())
