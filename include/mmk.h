@@ -185,6 +185,18 @@ int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, i
                            int32_t cart_pixel_width, float cart_resolution, float *grad_mask,
                            void *ws, size_t ws_bytes, void *stream);
 
+/* ---- loader primitives (icp_weight_dataset.py:323-362: PNG rows -> load_radar -> augmentation roll -> polar -> Cartesian)
+ * mmk_host_read_rows: HOST function, no GPU call, thread-safe: rows [0,rows) of a raw row-major byte file (header_bytes
+ * skipped, row_bytes per row; the decoded-scan cache / prepared-cloud cache of ICPWeightDataset), columns
+ * [col0, col0+ncols) kept, rows rotated as torch.roll(x, roll, dims=0) (the augmentation's azimuth roll, :446-452),
+ * written densely to dst (rows*ncols bytes; typically a slice of the batch's pinned buffer).
+ * mmk_u8_to_float: out[i] = lut256[in[i]] on the device -- load_radar's bytes / 255 (radar_utils.py:26) and the CFAR
+ * cache's (:343) with the table computed by the host's own fp32 division, so that the values are the reference's bit
+ * for bit whatever the device's division rounds to. */
+int mmk_host_read_rows(const char *path, int64_t header_bytes, int32_t rows, int32_t row_bytes, int32_t col0,
+                       int32_t ncols, int32_t roll, void *dst);
+int mmk_u8_to_float(const void *in /*n bytes*/, const float *lut256, int64_t n, float *out, void *stream);
+
 /* Statistics extract_weights returns next to the weights (radar_utils.py:130-138) and the policy's
  * mean_all_pts (icp_weight_policy.py:209-212), over the real points (not x==0 && y==0):
  * out[0] diff_mean_num_non0 = sum(0.5 tanh(5w)+0.5)/B, out[1] mean_num_non0 = count(w>0.05)/B,

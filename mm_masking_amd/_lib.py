@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SO_PATH = os.environ.get("MMK_LIB", os.path.join(_HERE, "libmmk_hip.so"))   # MMK_LIB: A/B another build (development)
-SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip", "mmk_unet_driver.hip"]
+SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip", "mmk_unet_driver.hip", "mmk_loader.hip"]
 
 _lib = None
 
@@ -156,6 +156,8 @@ def _declare(lib):
                                                   c_vp]),
         "mmk_cart_to_polar": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, i32, ctypes.c_double, c_vp, c_vp]),
         "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
+        "mmk_host_read_rows": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, i32, i32, i32, i32, i32, c_vp]),
+        "mmk_u8_to_float": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
         "mmk_sample_weights_bwd_ws_bytes": (sz, [i32, i32]),
         "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp, sz, c_vp]),
         "mmk_weight_stats": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),

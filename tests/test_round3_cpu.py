@@ -75,3 +75,59 @@ def test_worker_items_augmentation_matches_default_mode(golden_dir, tmp_path):
         torch.manual_seed(77 + i)
         b = ds.finish_batch(torch.utils.data.default_collate([wrk[i]]), "cpu", network_input_type="polar")
         _same(torch.utils.data.default_collate([a]), b)
+
+
+def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path):
+    """DeviceLoader's thread mode: ``fill_item`` (every tensor moved by mmk_host_read_rows: column cut + azimuth roll in C,
+    clouds from the prepared-cloud cache) + ``finish_batch`` (rotation of the clouds on the device) against the default
+    item mode under the same yaw draw: images, azimuths, poses, stamps bit-equal; rotated clouds to fp32 rounding."""
+    g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
+    pairs = _write_export(str(tmp_path), g)
+    ref = ds.ICPWeightDataset(pairs, dataset_params(augment=True), dataset_type="train", data_dir=str(tmp_path))
+    wrk = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train",
+                              data_dir=str(tmp_path))
+    wrk.T_loc_init = ref.T_loc_init.clone()
+    spec = wrk.native_item_spec()
+    for rep in range(2):                      # second round: every cache exists
+        for i in range(2):
+            bufs = {grp: {k: torch.empty((1,) + tuple(shape), dtype=dt) for k, (shape, dt) in d.items()} for grp, d in spec.items()}
+            torch.manual_seed(91 + i)
+            a = torch.utils.data.default_collate([ref[i]])
+            torch.manual_seed(91 + i)
+            wrk.fill_item(i, bufs, 0)
+            b = ds.finish_batch(bufs, "cpu", network_input_type="polar")
+            for key in ("fft_data", "fft_cfar", "timestamp"):
+                _same(a["loc_data"][key], b["loc_data"][key], key)
+            _same(a["transforms"], b["transforms"])
+            _same(a["map_data"]["timestamp"], b["map_data"]["timestamp"])
+            for x, y in ((a["loc_data"]["raw_pc"], b["loc_data"]["raw_pc"]), (a["loc_data"]["filtered_pc"], b["loc_data"]["filtered_pc"]),
+                         (a["map_data"]["pc"], b["map_data"]["pc"])):
+                assert x.shape == y.shape
+                np.testing.assert_allclose(y.numpy(), x.numpy(), rtol=2e-6, atol=2e-4)       # |pad value| = 1000: one fp32 ulp = 6e-5
+    assert os.path.isdir(os.path.join(wrk.pair_dirs[0], "prepared"))
+    # without augmentation the native path is bit-equal throughout
+    ref0 = ds.ICPWeightDataset(pairs, dataset_params(), dataset_type="train", data_dir=str(tmp_path))
+    wrk0 = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
+    wrk0.T_loc_init = ref0.T_loc_init.clone()
+    got = next(iter(ds.DeviceLoader(wrk0, batch_size=2, device="cpu", num_workers=3)))
+    _same(torch.utils.data.default_collate([ref0[0], ref0[1]]), got)
+
+
+def test_host_read_rows_roll_and_columns(tmp_path):
+    from mm_masking_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (7, 23), dtype=np.uint8)
+    path = str(tmp_path / "rows.u8")
+    with open(path, "wb") as f:
+        f.write(b"HEAD1234")
+        f.write(img.tobytes())
+    for roll in (0, 3, -2, 7, 9):
+        out = np.zeros((7, 10), np.uint8)
+        _lib.check(L.mmk_host_read_rows(path.encode(), 8, 7, 23, 5, 10, roll, out.ctypes.data))
+        assert np.array_equal(out, np.roll(img[:, 5:15], roll, axis=0)), roll
+    full = np.zeros((7, 23), np.uint8)
+    _lib.check(L.mmk_host_read_rows(path.encode(), 8, 7, 23, 0, 23, 0, full.ctypes.data))
+    assert np.array_equal(full, img)
+    assert L.mmk_host_read_rows(path.encode(), 8, 8, 23, 0, 23, 0, full.ctypes.data) != 0 and b"shorter" in L.mmk_last_error()
+    assert L.mmk_host_read_rows(str(tmp_path / "missing").encode(), 0, 1, 4, 0, 4, 0, full.ctypes.data) != 0
