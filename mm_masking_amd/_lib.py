@@ -78,13 +78,14 @@ def build(verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
+    per_file = {}            # (extra flags per source file: none at present)
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         deps = [src] + common + extra.get(os.path.basename(src), [])
         if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + per_file.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(o) for o in objs):
         return SO_PATH
 

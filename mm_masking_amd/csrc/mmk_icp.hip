@@ -477,6 +477,278 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// I2, the default brute-force engine for dim 2: the pre-filter of nn_prefilter_kernel with every (point, target) pair
+// priced on the MATRIX cores.  The fp32 VALU is what bounds the scan above (2 FMAs + 1/2 min per pair); the
+// bf16 matrix pipe runs beside the vector pipe and prices 32 x 32 pairs per v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD),
+// which leaves the vector pipe the chunk minima and the flags only: ~0.8 vector instructions per 64 pairs instead of 3.3.
+//
+// How a bf16 product gives an fp32-grade filter.  An fp32 number splits EXACTLY into three bf16 pieces, x = x1 + x2 + x3
+// (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 8 + 8 + 8 significant bits, |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|),
+// products of pieces are exact in fp32, and the matrix core accumulates in fp32.  With a = -2p (exact) and n = fl(|t|^2)
+// (formed in fp32 while the tile is staged: |n - |t|^2| <= 2u |t|^2, u = 2^-24), the 16 k-slots of one instruction hold
+//      k0..5   tx1 ax1, tx2 ax1, tx1 ax2, tx3 ax1, tx2 ax2, tx1 ax3        (= tx ax up to 2^-26 |tx ax|: the three
+//      k6..11  ty1 ay1, ty2 ay1, ty1 ay2, ty3 ay1, ty2 ay2, ty1 ay3         products left out are <= 2^-27, 2^-27, 2^-36)
+//      k12..14 n1 * 1, n2 * 1, n3 * 1;  k15 = 0
+// so that E_j = sum_k A[j][k] B[k][i] equals e_j = |t_j|^2 - 2 p_i . t_j = D_j - |p|^2 up to
+//      |E_j - e_j| <= 2u |t|^2 + u/2 |t||p| + 32.7u (|t|^2 + 2 |t||p|)
+// -- the last term for the accumulation of the <= 16 addends in WHATEVER order the hardware adds them, each addition charged
+// 2u of the sum of magnitudes S <= 1.02 (|t|^2 + 2|t||p|) (twice the rounding unit: also covers truncating adders).  With
+// |t| <= |p| + sqrt(D) and 2 |p| sqrt(D) <= |p|^2 + D:   |E_j - e_j| <= G(D_j),  G(D) = u (168.3 |p|^2 + 102.4 D).
+// The fp32 seed of the running bound (e of the previous iteration's correspondent, the fma chain of nn_prefilter_kernel)
+// errs by less than that.  Exactness then follows as above: j* the normative argmin, m the target whose computed value is
+// the running bound b, X = D_m: D_j* <= X (1 + 11u), so
+//      E_j* <= e_m + 11u X + G(X (1 + 11u)) <= b + G(X) + 11u X + G(X(1 + 11u)) <= b + u (336.6 |p|^2 + 216 X),
+//      X <= (b + |p|^2)(1 + 103u) + 169u |p|^2,
+// i.e. j* lies in a chunk whose minimum is <= thr(b), thr(b) = b + kappa (|p|^2 + (b + |p|^2)) = b (1 + kappa) + 2 kappa |p|^2,
+// kappa = 352u (15u |p|^2 of slack for the fp32 evaluation of thr; b + |p|^2 < 0 happens by rounding only, where X is
+// O(u |p|^2) and the term it multiplies is immaterial).  The kernel tests min < thr with kappa = 360u (strict: the chain of
+// v_min3 starts from thr itself), which flags whatever min <= thr flags at 352u: thr_360 - thr_352 = 8u (|p|^2 + D) > 0,
+// and c2 carries an absolute 1e-30 for the point that sits on the origin.  thr is monotone in b, every lane tests the 16 values it holds of a
+// 32-target chunk against ITS OWN running minimum (an upper bound of the true one: a superset of the chunks is flagged), the
+// two lanes that share a point OR their flag words, and the flagged chunks are re-scanned with nn_dist() from the fp32
+// planes kept in LDS next to the fragments -- ascending, strict '<': exactly the oracle's lowest-index argmin, as before
+// (tests/test_gpu_icp.py::test_nn_bit_exact and every ICP test; kappa is 7x the VALU filter's, which costs re-scans --
+// 0.03 m^2 of margin at 35 m from the sensor -- not correctness).
+// Layout: a block of 4 waves takes a source block of 512 points (the unit decomposition, XCD classes, zero-row lists and
+// 64-bit atomic-min merge are those of the kernels above); wave w holds 4 groups of 32 points as B operands (columns);
+// a tile of 1 024 targets sits in LDS as 32 A fragments [chunk][lane][8 bf16] (lane l: target l & 31, k = 8 (l >> 5) ...),
+// written by the thread that staged the target; the result tile has the point on the lane (column l & 31) and 16 targets
+// in the lane's registers.  For the re-scan and the output lane l owns the points of groups 2 (l >> 5) + {0, 1}.
+typedef __attribute__((ext_vector_type(8))) __bf16 nn_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float nn_f32x16;
+constexpr int NNM_GROUPS = 4;                      // 32-point groups per wave
+constexpr int NNM_PTS = NN_THREADS / 64 * NNM_GROUPS * 32;    // 512 points per block
+
+// D = A B (C = 0) with the result in VGPRs, where the vector pipe consumes it at once (gfx950's register file is unified).
+// Inline asm on purpose: through the builtin hipcc either returns the tile in AGPRs (16 v_accvgpr_read per instruction) or,
+// with -amdgpu-mfma-vgpr-form, lets the destination overlap the dying A operand -- which a multi-pass MFMA must not do (its
+// later passes still read it): correspondences then changed from run to run (scripts/nn_determinism.py).  "=&v" forbids the
+// overlap.  hipcc pads nothing around asm (cdna_hip_programming.md §5.7), so the software wait between an MFMA and the
+// first vector read of its result is explicit too (passes + 3 = 11 wait states for this 8-pass instruction, 19 if it were a
+// 16-pass one): see the chunk loop.
+__device__ __forceinline__ nn_f32x16 mfma_32x32x16_bf16_c0(nn_bf16x8 a, nn_bf16x8 b)
+{
+    nn_f32x16 d;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void split3(float x, __bf16 &x1, __bf16 &x2, __bf16 &x3)
+{
+    x1 = (__bf16)x;
+    const float r = x - (float)x1;
+    x2 = (__bf16)r;
+    x3 = (__bf16)(r - (float)x2);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(NN_THREADS) void nn_mfma_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgtp,
+    const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx,
+    const int32_t *__restrict__ ulist, const int32_t *__restrict__ ucnt, int ucap, int B,
+    int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
+    unsigned long long *__restrict__ packed)
+{
+    static_assert(DIM == 2 && NNM_GROUPS == 4, "the matrix-core filter is laid out for dim 2 (16 k-slots), 4 point groups per wave");
+    __shared__ __attribute__((aligned(16))) uint4 frag[NN_TILE / 32][64];        // 32 KB: A fragments of the tile
+    __shared__ __attribute__((aligned(16))) float lt[DIM][NN_TILE];               // 8 KB: the fp32 planes (exact re-scan)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int ntiles = Mpad / NN_TILE;
+    if (ulist != nullptr) total_units = ucnt[8] * ntu * 8;
+    const float kp1 = 1.0f + kappa;
+
+    // (static stride over the units, as in the kernels above.  A work queue -- one atomic draw per unit from a head per XCD
+    // class, issued a unit ahead -- was tried and lost 25-50 us per launch: the block-wide hand-over of the drawn unit costs
+    // more than the imbalance it removes.)
+    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+        const int xcd = u & 7;
+        int rest = u >> 3;
+        const int tu = rest % ntu;
+        rest /= ntu;
+        int sb, b;
+        if (ulist != nullptr) {
+            if (rest >= ucnt[xcd]) continue;
+            const int code = ulist[(size_t)xcd * ucap + rest];
+            sb = code & 0xfff;
+            b = code >> 12;
+        } else {
+            sb = rest % nsb;
+            b = (rest / nsb) * 8 + xcd;
+        }
+        if (b >= B) continue;
+        if (active != nullptr && active[b] == 0) continue;
+
+        float T[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
+        const float *tb = tgtp + (size_t)b * DIM * Mpad;
+
+        // ---- the wave's 4 x 32 points: this lane's column of every group (both lanes l, l + 32 of a column do the same)
+        float p[NNM_GROUPS][DIM], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS];
+        nn_bf16x8 bfr[NNM_GROUPS];
+        unsigned w[NNM_GROUPS];
+#pragma unroll
+        for (int g = 0; g < NNM_GROUPS; ++g) {
+            const int i = sb * NNM_PTS + wv * (NNM_GROUPS * 32) + g * 32 + col;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            if (i < N) {
+                const float *sp = src + ((size_t)b * N + i) * 3;
+                s0 = sp[0];
+                s1 = sp[1];
+                s2 = sp[2];
+            }
+            const float s[3] = {s0, s1, s2};
+            transform_point<DIM>(T, s, p[g]);
+            const float pn = p[g][0] * p[g][0] + p[g][1] * p[g][1];
+            c2[g] = 2.0f * kappa * pn + 1e-30f;
+            const float ax = -2.0f * p[g][0], ay = -2.0f * p[g][1];
+            __bf16 ax1, ax2, ax3, ay1, ay2, ay3;
+            split3(ax, ax1, ax2, ax3);
+            split3(ay, ay1, ay2, ay3);
+            const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+            const nn_bf16x8 lo = {ax1, ax1, ax2, ax1, ax2, ax3, ay1, ay1};
+            const nn_bf16x8 hi = {ay2, ay1, ay2, ay3, one, one, one, zero};
+            bfr[g] = half ? hi : lo;
+            // any e_j bounds the minimum: start from the previous iteration's correspondent (fp32 chain of the filter above)
+            float b0 = INFINITY;
+            if (prev_idx != nullptr && i < N) {
+                const int j = prev_idx[(size_t)b * N + i];
+                if (j >= 0 && j < Mpad) {
+                    const float jx = tb[j], jy = tb[(size_t)Mpad + j];
+                    const float jn = __builtin_fmaf(jy, jy, jx * jx);
+                    b0 = __builtin_fmaf(jx, ax, __builtin_fmaf(jy, ay, jn));
+                    b0 = (b0 == b0) ? b0 : INFINITY;
+                }
+            }
+            brun[g] = b0;
+            thr[g] = __builtin_fmaf(b0, kp1, c2[g]);
+        }
+        // ---- the two points this lane owns for the exact part
+        float po[2][DIM], cur[2];
+        int pidx[2], jj[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) po[q][c] = half ? p[2 + q][c] : p[q][c];
+            pidx[q] = sb * NNM_PTS + wv * (NNM_GROUPS * 32) + (2 * half + q) * 32 + col;
+            cur[q] = INFINITY;
+        }
+
+        const int t0 = tu * tiles_per_unit;
+        const int t1 = min(ntiles, t0 + tiles_per_unit);
+        jj[0] = jj[1] = t0 * NN_TILE;
+
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();
+            {   // stage: this thread's 4 targets -> the fp32 planes and rows 4 (tid % 8) .. + 3 of fragment tid / 8
+                const float4 vx = *reinterpret_cast<const float4 *>(tb + (size_t)t * NN_TILE + tid * 4);
+                const float4 vy = *reinterpret_cast<const float4 *>(tb + (size_t)Mpad + (size_t)t * NN_TILE + tid * 4);
+                *reinterpret_cast<float4 *>(&lt[0][tid * 4]) = vx;
+                *reinterpret_cast<float4 *>(&lt[1][tid * 4]) = vy;
+                const float xs[4] = {vx.x, vx.y, vx.z, vx.w}, ys[4] = {vy.x, vy.y, vy.z, vy.w};
+                uint4 *fr = &frag[tid >> 3][(tid & 7) * 4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float n = __builtin_fmaf(ys[r], ys[r], xs[r] * xs[r]);
+                    __bf16 x1, x2, x3, y1, y2, y3, n1, n2, n3;
+                    split3(xs[r], x1, x2, x3);
+                    split3(ys[r], y1, y2, y3);
+                    split3(n, n1, n2, n3);
+                    const nn_bf16x8 lo = {x1, x2, x1, x3, x2, x1, y1, y2};
+                    const nn_bf16x8 hi = {y1, y3, y2, y1, n1, n2, n3, (__bf16)0.0f};
+                    fr[r] = __builtin_bit_cast(uint4, lo);
+                    fr[32 + r] = __builtin_bit_cast(uint4, hi);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < NNM_GROUPS; ++g) w[g] = 0u;
+            // (tried, no gain: a software pipeline one chunk deep -- the MFMAs of chunk c + 1 issued between the reductions of
+            // chunk c, pinned with sched_group_barrier: 173-199 VGPRs, two waves per SIMD instead of three, 20 % slower)
+            auto reduce = [&](const nn_f32x16 &acc, int g) {
+                // t = min(thr, chunk minimum): the chain starts from thr (a canonical fp32 value, so that no input of the
+                // v_min3 chain needs quieting), the chunk is flagged when t < thr, and min(brun, t) is the new bound either way
+                // (a tree, depth 3: a chain of 8 dependent v_min3 is latency-bound with 2-3 waves per SIMD)
+                auto m3 = [](float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); };
+                const float m0 = m3(thr[g], acc[0], acc[1]), m1 = m3(acc[2], acc[3], acc[4]), m2 = m3(acc[5], acc[6], acc[7]);
+                const float m4 = m3(acc[8], acc[9], acc[10]), m5 = m3(acc[11], acc[12], acc[13]);
+                const float n0 = m3(m0, m1, m2), n1 = m3(m4, m5, acc[14]);
+                const float t = m3(n0, n1, acc[15]);
+                w[g] = (w[g] << 1) | ((t < thr[g]) ? 1u : 0u);         // chunk c ends up in bit 31 - c
+                brun[g] = __builtin_fminf(brun[g], t);
+                thr[g] = __builtin_fmaf(brun[g], kp1, c2[g]);
+            };
+            uint4 af_next = frag[0][lane];
+#pragma unroll 2
+            for (int c = 0; c < NN_TILE / 32; ++c) {
+                const nn_bf16x8 af = __builtin_bit_cast(nn_bf16x8, af_next);
+                af_next = frag[(c + 1) & (NN_TILE / 32 - 1)][lane];          // next chunk's fragment in flight behind this chunk's MFMAs
+                nn_f32x16 acc[NNM_GROUPS];
+#pragma unroll
+                for (int g = 0; g < NNM_GROUPS; ++g) acc[g] = mfma_32x32x16_bf16_c0(af, bfr[g]);
+                // MFMA g + 1 enters the matrix pipe when MFMA g leaves it, so results 0..2 are complete 4 wait states behind
+                // the last issue; result 3 is read behind the three reductions (~40 vector instructions), which the second
+                // statement is tied to through their outputs
+                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+                reduce(acc[0], 0);
+                reduce(acc[1], 1);
+                reduce(acc[2], 2);
+                asm volatile("" : "+v"(acc[3]), "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]));
+                reduce(acc[3], 3);
+            }
+            // ---- flags of the two lanes that share a point, then the exact re-scan of this tile's flagged chunks while
+            // the tile is in LDS (chunks ascending, tiles ascending, strict '<': the lowest index among equal distances)
+            unsigned wo[2];
+            {
+                unsigned wf[NNM_GROUPS];
+#pragma unroll
+                for (int g = 0; g < NNM_GROUPS; ++g) wf[g] = w[g] | (unsigned)__shfl_xor((int)w[g], 32, 64);
+                wo[0] = half ? wf[2] : wf[0];
+                wo[1] = half ? wf[3] : wf[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned ww = wo[q];
+                while (__any(ww != 0u)) {
+                    if (ww != 0u) {
+                        const int c = __clz((int)ww);
+                        ww &= ~(0x80000000u >> c);
+                        const int o0 = c * 32;
+                        float best = INFINITY;
+                        int bj = 0;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
+                            const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
+                            const float d0 = nn_dist<DIM>(vx.x, vy.x, 0.f, po[q]), d1 = nn_dist<DIM>(vx.y, vy.y, 0.f, po[q]);
+                            const float d2 = nn_dist<DIM>(vx.z, vy.z, 0.f, po[q]), d3 = nn_dist<DIM>(vx.w, vy.w, 0.f, po[q]);
+                            if (d0 < best) { best = d0; bj = h * 4 + 0; }
+                            if (d1 < best) { best = d1; bj = h * 4 + 1; }
+                            if (d2 < best) { best = d2; bj = h * 4 + 2; }
+                            if (d3 < best) { best = d3; bj = h * 4 + 3; }
+                        }
+                        if (best < cur[q]) {
+                            cur[q] = best;
+                            jj[q] = t * NN_TILE + o0 + bj;
+                        }
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = pidx[q];
+            if (i >= N) continue;
+            if (!(cur[q] < INFINITY) && tu != 0) continue;
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(cur[q]) << 32) | (unsigned long long)(unsigned)jj[q];
+            atomicMin(&packed[(size_t)b * N + i], key);
+        }
+    }
+}
+
 constexpr unsigned long long NN_KEY_INIT = ~0ull;
 
 __global__ void nn_unpack_kernel(const unsigned long long *__restrict__ packed, int n, int32_t *__restrict__ idx,
@@ -1256,6 +1528,7 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 struct NNPlan {
     int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P, ucap;
     bool prefilter;
+    bool mfma;      // dim 2: the filter runs on the matrix cores (nn_mfma_kernel)
 };
 
 
@@ -1301,7 +1574,18 @@ struct NNTune {
     }
 };
 
-NNPlan nn_plan(int B, int N, int M)
+// MMK_NN_MFMA=0: price the pairs of the dim-2 filter on the vector pipe (nn_prefilter_kernel) -- A/B measurements
+bool use_nn_mfma()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMK_NN_MFMA");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+NNPlan nn_plan(int B, int N, int M, int dim)
 {
     static const NNTune tune;
     NNPlan pl;
@@ -1311,6 +1595,7 @@ NNPlan nn_plan(int B, int N, int M)
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
     pl.prefilter = use_nn_prefilter() && (pl.P == 2 || pl.P == 4);
+    pl.mfma = pl.prefilter && dim == 2 && pl.P == 2 && use_nn_mfma();       // (same 512-point source blocks as P = 2)
     // (pre-filtered scan: short ranges balance the CUs better, and a range without candidates below the starting bound
     // costs no atomic.  Bench shape, 20 tiles: 5 tiles per unit 224 us, 2 tiles 216 us; with the zero-row blocks gone from
     // the unit list 5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch)
@@ -1320,8 +1605,9 @@ NNPlan nn_plan(int B, int N, int M)
     const int Bpad = (B + 7) / 8 * 8;
     pl.total_units = Bpad * pl.nsb * pl.ntu;
     pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
-    // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs)
-    pl.grid = std::min(pl.total_units, 2048);
+    // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs); 3 of the matrix-core
+    // kernel's (40 KB of LDS each)
+    pl.grid = std::min(pl.total_units, pl.mfma ? 768 : 2048);
     return pl;
 }
 
@@ -1349,6 +1635,26 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    if (pl.mfma && dim == 2) {
+        constexpr float U = 5.9604645e-8f;       // 2^-24
+        // Units of 4 tiles: a lane's running bound restarts with every unit, and without a seed (the first ICP iteration) every
+        // restart flags a "record" sequence of chunks that the exact part then re-scans: 324 / 170 us for the first / a later
+        // launch at 1 tile per unit, 265 / 162 at 2, 226 / 157 at 4.
+        static const NNTune tune;
+        const int tpu = tune.user ? pl.tiles_per_unit : std::min(4, pl.ntiles);
+        const int ntu = (pl.ntiles + tpu - 1) / tpu;
+        const int Bpad = (B + 7) / 8 * 8;
+        const int total_units = Bpad * pl.nsb * ntu;
+        // persistent grid: 3 blocks of 256 threads per CU (40 KB of LDS, <= 168 VGPRs)
+        hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(std::min(total_units, 768)), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx,
+                           ulist, ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, ntu, tpu, total_units, 360.0f * U, packed);
+        MMK_LAUNCH_CHECK();
+        if (rec) {
+            MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+            g_prof.n++;
+        }
+        return MMK_OK;
+    }
     if (pl.prefilter) {
         constexpr float U = 5.9604645e-8f;       // 2^-24
 #define MMK_PF_CASE(D, PP, SB, KAPPA)                                                                                     \
@@ -1411,7 +1717,7 @@ struct IcpWs {
 
 IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
 {
-    const NNPlan pl = nn_plan(p->B, p->N, p->M);
+    const NNPlan pl = nn_plan(p->B, p->N, p->M, p->dim);
     const int nblk = (p->N + ACC_THREADS - 1) / ACC_THREADS;
     mmk::Arena ar(ws, cap);
     IcpWs w;
@@ -1444,7 +1750,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
                 int *iters_run, hipStream_t st)
 {
     const int B = p->B, N = p->N, M = p->M;
-    const NNPlan pl = nn_plan(B, N, M);
+    const NNPlan pl = nn_plan(B, N, M, DIM);
     const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
@@ -1591,7 +1897,7 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     MMK_REQUIRE(source && target_planar && T && idx && d2, "mmk_nn_search: NULL pointer");
     MMK_REQUIRE(B >= 1 && N >= 1 && M >= 1, "mmk_nn_search: B, N, M must be >= 1");
     MMK_REQUIRE(dim == 2 || dim == 3, "mmk_nn_search: dim must be 2 or 3");
-    const NNPlan pl = nn_plan(B, N, M);
+    const NNPlan pl = nn_plan(B, N, M, dim);
     mmk::Arena ar(workspace, workspace_bytes);
     unsigned long long *packed = ar.take<unsigned long long>((size_t)B * N);
     if (!ar.ok() || workspace == nullptr) {

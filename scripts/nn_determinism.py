@@ -1,0 +1,29 @@
+"""dICP forward at the bench shape twice on identical inputs: correspondences of every iteration must be bit-identical run to
+run (and equal between NN engines: run once more with MMK_NN_MFMA=0 and compare the printed checksums)."""
+import os, sys, hashlib
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mm_masking_amd import synthetic, train_icp_weights as trn
+from mm_masking_amd.dICP.ICP import ICP
+B = 32
+dev = torch.device("cuda:0")
+params = trn.default_params(dev)
+raw = synthetic.make_batch(list(range(4000, 4000 + B)), device=dev)
+batch = trn.prepare_batch(raw, params)
+src = batch["loc_data"]["filtered_pc"]
+torch.manual_seed(5)
+w0 = torch.rand(B, src.shape[1], device=dev)
+icp = ICP("pt2pl", differentiable=True, max_iterations=10, tolerance=1e-5)
+outs = []
+for rep in range(4):
+    w = w0.clone().requires_grad_(True)
+    T = icp.icp(src, raw["map_pc"], T_init=raw["T_init"], weight=w, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)["T"]
+    idx = T.grad_fn.saved_tensors[3].cpu().numpy()
+    outs.append((idx.copy(), T.detach().cpu().numpy().copy()))
+    # churn the GPU differently between repetitions
+    x = torch.randn(4096, 4096, device=dev); (x @ x).sum().item()
+for rep in range(1, 4):
+    d = (outs[rep][0] != outs[0][0])
+    print("rep", rep, "idx mismatches", int(d.sum()), "by iteration", d.reshape(10, -1).sum(axis=1).tolist(), "T equal", np.array_equal(outs[rep][1], outs[0][1]))
+print("idx md5", hashlib.md5(outs[0][0].tobytes()).hexdigest(), "T md5", hashlib.md5(outs[0][1].tobytes()).hexdigest())
