@@ -707,32 +707,34 @@ __global__ __launch_bounds__(NN_THREADS) void nn_mfma_kernel(
                 wo[0] = half ? wf[2] : wf[0];
                 wo[1] = half ? wf[3] : wf[1];
             }
+            // (one loop over the flags of both points a lane owns: the wave leaves it after max over lanes of (flags of point 0 +
+            // flags of point 1) rounds instead of the sum of the two maxima)
+            while (__any((wo[0] | wo[1]) != 0u)) {
+                if ((wo[0] | wo[1]) != 0u) {
+                    const bool second = wo[0] == 0u;
+                    const unsigned ww = second ? wo[1] : wo[0];
+                    const int c = __clz((int)ww);
+                    const unsigned rest = ww & ~(0x80000000u >> c);
+                    wo[0] = second ? wo[0] : rest;
+                    wo[1] = second ? rest : wo[1];
+                    const float pq[DIM] = {second ? po[1][0] : po[0][0], second ? po[1][1] : po[0][1]};
+                    const int o0 = c * 32;
+                    float best = INFINITY;
+                    int bj = 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                unsigned ww = wo[q];
-                while (__any(ww != 0u)) {
-                    if (ww != 0u) {
-                        const int c = __clz((int)ww);
-                        ww &= ~(0x80000000u >> c);
-                        const int o0 = c * 32;
-                        float best = INFINITY;
-                        int bj = 0;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) {
-                            const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
-                            const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
-                            const float d0 = nn_dist<DIM>(vx.x, vy.x, 0.f, po[q]), d1 = nn_dist<DIM>(vx.y, vy.y, 0.f, po[q]);
-                            const float d2 = nn_dist<DIM>(vx.z, vy.z, 0.f, po[q]), d3 = nn_dist<DIM>(vx.w, vy.w, 0.f, po[q]);
-                            if (d0 < best) { best = d0; bj = h * 4 + 0; }
-                            if (d1 < best) { best = d1; bj = h * 4 + 1; }
-                            if (d2 < best) { best = d2; bj = h * 4 + 2; }
-                            if (d3 < best) { best = d3; bj = h * 4 + 3; }
-                        }
-                        if (best < cur[q]) {
-                            cur[q] = best;
-                            jj[q] = t * NN_TILE + o0 + bj;
-                        }
+                    for (int h = 0; h < 8; ++h) {
+                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
+                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
+                        const float d0 = nn_dist<DIM>(vx.x, vy.x, 0.f, pq), d1 = nn_dist<DIM>(vx.y, vy.y, 0.f, pq);
+                        const float d2 = nn_dist<DIM>(vx.z, vy.z, 0.f, pq), d3 = nn_dist<DIM>(vx.w, vy.w, 0.f, pq);
+                        if (d0 < best) { best = d0; bj = h * 4 + 0; }
+                        if (d1 < best) { best = d1; bj = h * 4 + 1; }
+                        if (d2 < best) { best = d2; bj = h * 4 + 2; }
+                        if (d3 < best) { best = d3; bj = h * 4 + 3; }
                     }
+                    const int jn = t * NN_TILE + o0 + bj;
+                    if (!second && best < cur[0]) { cur[0] = best; jj[0] = jn; }
+                    if (second && best < cur[1]) { cur[1] = best; jj[1] = jn; }
                 }
             }
         }
