@@ -455,8 +455,7 @@ def main():
         # source rows a launch actually scans: blocks of 512 all-zero padding rows behind a pair's first zero row take that
         # row's result instead (csrc/mmk_icp.hip: src_zero_scan_kernel) -- the evaluation count follows the rows scanned
         scanned = float(N_PAD)
-        if model.ICP_alg.nn_search == "brute" and os.environ.get("MMK_NN_ZERO_DEDUP", "1") != "0" and \
-                os.environ.get("MMK_NN_PREFILTER", "1") != "0":
+        if model.ICP_alg.nn_search == "brute":
             src_pts = trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD)["loc_data"]["filtered_pc"]
             zero = (src_pts == 0).all(dim=-1)                                     # (B,N)
             first_zero = torch.where(zero.any(dim=1), zero.float().argmax(dim=1), torch.full((B,), N_PAD, device=device))
@@ -481,12 +480,9 @@ def main():
         valid = valid_scan_points(trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD))
         # bytes a launch actually reads + writes: the scanned source rows (x,y), the target planes, one (idx, d2) per row
         alg_bytes_read = active_pairs * (4 * DIM * scanned + 4 * DIM * M_PAD + 8 * N_PAD)
-        mfma_nn = (model.ICP_alg.nn_search == "brute" and DIM == 2 and os.environ.get("MMK_NN_MFMA", "1") != "0"
-                   and os.environ.get("MMK_NN_PREFILTER", "1") != "0")
+        mfma_nn = model.ICP_alg.nn_search == "brute" and DIM == 2 and os.environ.get("MMK_NN_MFMA", "1") != "0"
         if model.ICP_alg.nn_search == "grid":
             nn_kernel = "grid_nn_kernel<2>"
-        elif os.environ.get("MMK_NN_PREFILTER", "1") == "0":
-            nn_kernel = "nn_search_kernel<2, 16, 2>"
         else:
             nn_kernel = "nn_mfma_kernel<2>" if mfma_nn else "nn_prefilter_kernel<2, 2, 16>"
         if mfma_nn:

@@ -72,137 +72,15 @@ __global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int col
 }
 
 // ------------------------------------------------------------------------------------------
-// I2: brute-force NN.  One lane owns P transformed source points in VGPRs; the target
-// streams through LDS in planar tiles (wave-uniform ds_read_b128 broadcasts).  Per chunk
-// of CHUNK targets only the chunk minimum is tracked (v_min3) together with the id of the
-// first chunk that attained it; the winning chunk is re-scanned at the end with a strict
-// '<' in ascending order, which yields exactly the lowest-index argmin of the oracle.
-// Work is cut into units (pair, source block, target range); a persistent 1-D grid walks
-// them with stride gridDim.x.  Units are numbered so that unit % 8 == pair % 8: blocks of
-// one pair share an XCD (blockIdx % 8 label) and its target planes stay in that L2.
-// The partial results of the target ranges meet in one 64-bit atomic min per source point
-// on the key (float bits of d2) << 32 | index: d2 >= 0, so unsigned order == float order,
-// and equal distances resolve to the lowest index; min is order independent, so the
-// result is deterministic.
-template <int DIM, int CHUNK, int P>
-__global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
-    const float *__restrict__ src, const float *__restrict__ tgtp, const float *__restrict__ Tk,
-    const int32_t *__restrict__ active, int B, int N, int Mpad, int nsb, int ntu, int tiles_per_unit,
-    int total_units, unsigned long long *__restrict__ packed)
-{
-    __shared__ __attribute__((aligned(16))) float lt[DIM][NN_TILE];
-    const int tid = threadIdx.x;
-    const int ntiles = Mpad / NN_TILE;
-
-    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
-        const int xcd = u & 7;
-        int rest = u >> 3;
-        const int tu = rest % ntu;
-        rest /= ntu;
-        const int sb = rest % nsb;
-        const int b = (rest / nsb) * 8 + xcd;
-        if (b >= B) continue;
-        if (active != nullptr && active[b] == 0) continue;
-
-        float T[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
-
-        float p[P][DIM];
-        float best[P];
-        int bch[P];
-        int pidx[P];
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = sb * (NN_THREADS * P) + q * NN_THREADS + tid;
-            pidx[q] = i;
-            float s[3] = {0.f, 0.f, 0.f};
-            if (i < N) {
-                const float *sp = src + ((size_t)b * N + i) * 3;
-                s[0] = sp[0];
-                s[1] = sp[1];
-                s[2] = sp[2];
-            }
-            transform_point<DIM>(T, s, p[q]);
-            best[q] = INFINITY;
-            bch[q] = 0;
-        }
-
-        const int t0 = tu * tiles_per_unit;
-        const int t1 = min(ntiles, t0 + tiles_per_unit);
-        const float *tb = tgtp + (size_t)b * DIM * Mpad;
-
-        for (int t = t0; t < t1; ++t) {
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                // NN_TILE floats per plane = 256 lanes x float4
-                const float4 v =
-                    *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
-                *reinterpret_cast<float4 *>(&lt[c][tid * 4]) = v;
-            }
-            __syncthreads();
-            const int chunk0 = t * (NN_TILE / CHUNK);
-#pragma unroll 2
-            for (int c = 0; c < NN_TILE / CHUNK; ++c) {
-                float tx[CHUNK], ty[CHUNK], tz[CHUNK];
-#pragma unroll
-                for (int h = 0; h < CHUNK / 4; ++h) {
-                    const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][c * CHUNK + h * 4]);
-                    const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][c * CHUNK + h * 4]);
-                    tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
-                    ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
-                    if (DIM == 3) {
-                        const float4 vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][c * CHUNK + h * 4]);
-                        tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
-                    } else {
-                        tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    float m = nn_dist<DIM>(tx[0], ty[0], tz[0], p[q]);
-#pragma unroll
-                    for (int j = 1; j + 1 < CHUNK; j += 2)
-                        m = __builtin_fminf(__builtin_fminf(m, nn_dist<DIM>(tx[j], ty[j], tz[j], p[q])),
-                                            nn_dist<DIM>(tx[j + 1], ty[j + 1], tz[j + 1], p[q]));
-                    m = __builtin_fminf(m, nn_dist<DIM>(tx[CHUNK - 1], ty[CHUNK - 1], tz[CHUNK - 1], p[q]));
-                    const bool better = m < best[q];
-                    best[q] = better ? m : best[q];
-                    bch[q] = better ? (chunk0 + c) : bch[q];
-                }
-            }
-        }
-
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = pidx[q];
-            if (i >= N) continue;
-            const int j0 = bch[q] * CHUNK;
-            float cur = INFINITY;
-            int jj = j0;
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) {
-                const float tx = tb[j0 + j];
-                const float ty = tb[(size_t)Mpad + j0 + j];
-                const float tz = (DIM == 3) ? tb[(size_t)2 * Mpad + j0 + j] : 0.f;
-                const float d = nn_dist<DIM>(tx, ty, tz, p[q]);
-                if (d < cur) {
-                    cur = d;
-                    jj = j0 + j;
-                }
-            }
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(cur) << 32) | (unsigned long long)(unsigned)jj;
-            atomicMin(&packed[(size_t)b * N + i], key);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// I2 with an exact pre-filter (the default brute-force engine).  The scan above spends 4.5 vector
-// lane-operations per (point, target) pair on d = fma(dy, dy, dx * dx) and the fp32 VALU is what bounds it
-// (DESIGN.md §5).  Here every pair is first priced with the expanded form
+// I2: brute-force NN with an exact pre-filter, priced on the vector pipe (dim 3; the dim-2 form on the matrix cores follows).
+// One lane owns P transformed source points in VGPRs; the target streams through LDS in planar tiles (wave-uniform
+// ds_read_b128 broadcasts).  Work is cut into units (pair, source block, target range); a persistent 1-D grid walks them with
+// stride gridDim.x.  Units are numbered so that unit % 8 == pair % 8: blocks of one pair share an XCD (blockIdx % 8 label) and
+// its target planes stay in that L2.  The partial results of the target ranges meet in one 64-bit atomic min per source point
+// on the key (float bits of d2) << 32 | index: d2 >= 0, so unsigned order == float order, and equal distances resolve to the
+// lowest index; min is order independent, so the result is deterministic.
+// A plain scan spends 4.5 vector lane-operations per (point, target) pair on d = fma(dy, dy, dx * dx) (round 1's kernel:
+// bound by the fp32 VALU).  Here every pair is first priced with the expanded form
 //      e_j = fma(tx_j, a, fma(ty_j, b, tn_j)),   a = -2 px, b = -2 py,  tn_j = |t_j|^2 (formed once per target while
 //      its tile is staged into LDS)              -> 2 lane-operations (+ 1/2 for the running minimum)
 // which equals D_j - |p|^2 up to rounding, D_j the true squared distance.  Still exhaustive: every target is
@@ -221,7 +99,6 @@ __global__ __launch_bounds__(NN_THREADS) void nn_search_kernel(
 // order with a strict '<', which yields exactly the lowest-index argmin of the oracle (oracle/nn_search.c):
 // tests/test_gpu_icp.py::test_nn_bit_exact.  b_run starts from e of the previous iteration's correspondent (any
 // e_j bounds the minimum), so after the first iteration little more than the chunks that matter is flagged.
-// Work decomposition, XCD mapping and the 64-bit atomic-min merge of the target ranges are those of the scan above.
 constexpr int PF_CH = 32;            // targets per flag bit (32 chunks per LDS tile: one flag word per point and tile)
 
 // Identical source rows have identical nearest neighbours.  The reference pads every scan with all-zero rows up to the
@@ -1528,53 +1405,10 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
-    int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, chunk, P, ucap;
-    bool prefilter;
+    int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, P, ucap;
     bool mfma;      // dim 2: the filter runs on the matrix cores (nn_mfma_kernel)
 };
 
-
-// MMK_NN_ZERO_DEDUP=0: scan the all-zero padding rows of the source like any other row (A/B measurements)
-bool use_zero_dedup()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MMK_NN_ZERO_DEDUP");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-// MMK_NN_PREFILTER=0 selects the plain scan (nn_search_kernel) instead of the pre-filtered one: same results,
-// A/B measurements (scripts/bench_nn.py)
-bool use_nn_prefilter()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MMK_NN_PREFILTER");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-// Tuning knobs of the NN kernel; MMK_NN_VARIANT = "<chunk>,<P>,<tiles_per_unit>" overrides
-// them for experiments (scripts/bench_nn.py).
-struct NNTune {
-    int chunk = 16, P = 2, tiles_per_unit = 5;
-    bool user = false;
-    NNTune()
-    {
-        if (const char *e = getenv("MMK_NN_VARIANT")) {
-            int c = 0, p = 0, t = 0;
-            if (sscanf(e, "%d,%d,%d", &c, &p, &t) == 3 && (c == 8 || c == 16) && (p == 1 || p == 2 || p == 4) && t >= 1) {
-                chunk = c;
-                P = p;
-                tiles_per_unit = t;
-                user = true;
-            }
-        }
-    }
-};
 
 // MMK_NN_MFMA=0: price the pairs of the dim-2 filter on the vector pipe (nn_prefilter_kernel) -- A/B measurements
 bool use_nn_mfma()
@@ -1589,26 +1423,24 @@ bool use_nn_mfma()
 
 NNPlan nn_plan(int B, int N, int M, int dim)
 {
-    static const NNTune tune;
     NNPlan pl;
-    pl.chunk = tune.chunk;
-    pl.P = tune.P;
+    pl.P = 2;                                   // points per lane of the vector-pipe filter = 512-point source blocks for both kernels
     pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
-    pl.prefilter = use_nn_prefilter() && (pl.P == 2 || pl.P == 4);
-    pl.mfma = pl.prefilter && dim == 2 && pl.P == 2 && use_nn_mfma();       // (same 512-point source blocks as P = 2)
-    // (pre-filtered scan: short ranges balance the CUs better, and a range without candidates below the starting bound
-    // costs no atomic.  Bench shape, 20 tiles: 5 tiles per unit 224 us, 2 tiles 216 us; with the zero-row blocks gone from
-    // the unit list 5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch)
-    pl.tiles_per_unit = std::min((pl.prefilter && !tune.user) ? 1 : tune.tiles_per_unit, pl.ntiles);
-
+    pl.mfma = dim == 2 && use_nn_mfma();
+    // Vector-pipe filter: single tiles -- short ranges balance the CUs better, and a range without candidates below the starting
+    // bound costs no atomic (5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch).  Matrix-core filter: a lane's
+    // running bound restarts with every unit, and without a seed (the first ICP iteration) every restart flags a "record"
+    // sequence of chunks that the exact part then re-scans: 324 / 170 us for the first / a later launch at 1 tile per unit,
+    // 265 / 162 at 2, 226 / 157 at 4.
+    pl.tiles_per_unit = std::min(pl.mfma ? 4 : 1, pl.ntiles);
     pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
     pl.total_units = Bpad * pl.nsb * pl.ntu;
     pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
     // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs); 3 of the matrix-core
-    // kernel's (40 KB of LDS each)
+    // kernel's (40 KB of LDS each, <= 168 VGPRs)
     pl.grid = std::min(pl.total_units, pl.mfma ? 768 : 2048);
     return pl;
 }
@@ -1620,15 +1452,7 @@ struct NNProf {
     int cap = 0, n = 0;
     hipEvent_t *ev = nullptr;  // 2 * cap
 };
-NNProf g_prof;
-
-template <int DIM, int CHUNK, int P>
-void launch_nn_t(const float *src, const float *tgtp, const float *Tk, const int32_t *active, int B, int N,
-                 const NNPlan &pl, unsigned long long *packed, hipStream_t st)
-{
-    hipLaunchKernelGGL((nn_search_kernel<DIM, CHUNK, P>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active,
-                       B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, packed);
-}
+thread_local NNProf g_prof;      // per host thread: the library keeps no process-global mutable state
 
 // `packed` (B,N) must hold NN_KEY_INIT on entry (memset 0xFF or re-armed by the accumulate kernel).
 int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active,
@@ -1637,49 +1461,17 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    constexpr float U = 5.9604645e-8f;       // 2^-24
     if (pl.mfma && dim == 2) {
-        constexpr float U = 5.9604645e-8f;       // 2^-24
-        // Units of 4 tiles: a lane's running bound restarts with every unit, and without a seed (the first ICP iteration) every
-        // restart flags a "record" sequence of chunks that the exact part then re-scans: 324 / 170 us for the first / a later
-        // launch at 1 tile per unit, 265 / 162 at 2, 226 / 157 at 4.
-        static const NNTune tune;
-        const int tpu = tune.user ? pl.tiles_per_unit : std::min(4, pl.ntiles);
-        const int ntu = (pl.ntiles + tpu - 1) / tpu;
-        const int Bpad = (B + 7) / 8 * 8;
-        const int total_units = Bpad * pl.nsb * ntu;
-        // persistent grid: 3 blocks of 256 threads per CU (40 KB of LDS, <= 168 VGPRs)
-        hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(std::min(total_units, 768)), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx,
-                           ulist, ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, ntu, tpu, total_units, 360.0f * U, packed);
-        MMK_LAUNCH_CHECK();
-        if (rec) {
-            MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
-            g_prof.n++;
-        }
-        return MMK_OK;
+        hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist, ucnt,
+                           pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 360.0f * U, packed);
+    } else if (dim == 2) {
+        hipLaunchKernelGGL((nn_prefilter_kernel<2, 2, 16>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist,
+                           ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 48.0f * U, packed);
+    } else {
+        hipLaunchKernelGGL((nn_prefilter_kernel<3, 2, 16>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist,
+                           ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 64.0f * U, packed);
     }
-    if (pl.prefilter) {
-        constexpr float U = 5.9604645e-8f;       // 2^-24
-#define MMK_PF_CASE(D, PP, SB, KAPPA)                                                                                     \
-    if (dim == D && pl.P == PP && pl.chunk == SB)                                                                        \
-        hipLaunchKernelGGL((nn_prefilter_kernel<D, PP, SB>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, \
-                           prev_idx, ulist, ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, KAPPA * U, packed)
-        MMK_PF_CASE(2, 2, 16, 48.0f); MMK_PF_CASE(2, 4, 16, 48.0f); MMK_PF_CASE(3, 2, 16, 64.0f); MMK_PF_CASE(3, 4, 16, 64.0f);
-        MMK_PF_CASE(2, 2, 8, 48.0f); MMK_PF_CASE(2, 4, 8, 48.0f); MMK_PF_CASE(3, 2, 8, 64.0f); MMK_PF_CASE(3, 4, 8, 64.0f);
-#undef MMK_PF_CASE
-        MMK_LAUNCH_CHECK();
-        if (rec) {
-            MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
-            g_prof.n++;
-        }
-        return MMK_OK;
-    }
-#define MMK_NN_CASE(D, C, PP) \
-    if (dim == D && pl.chunk == C && pl.P == PP) launch_nn_t<D, C, PP>(src, tgtp, Tk, active, B, N, pl, packed, st)
-    MMK_NN_CASE(2, 8, 1); MMK_NN_CASE(2, 8, 2); MMK_NN_CASE(2, 8, 4);
-    MMK_NN_CASE(2, 16, 1); MMK_NN_CASE(2, 16, 2); MMK_NN_CASE(2, 16, 4);
-    MMK_NN_CASE(3, 8, 1); MMK_NN_CASE(3, 8, 2); MMK_NN_CASE(3, 8, 4);
-    MMK_NN_CASE(3, 16, 1); MMK_NN_CASE(3, 16, 2); MMK_NN_CASE(3, 16, 4);
-#undef MMK_NN_CASE
     MMK_LAUNCH_CHECK();
     if (rec) {
         MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
@@ -1759,7 +1551,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)2 * B * N, st));
     const bool use_grid = p->nn_method == MMK_NN_GRID;
     const int nn_pts = NN_THREADS * pl.P;
-    const bool dedup = !use_grid && pl.prefilter && use_zero_dedup() && pl.nsb <= 0xfff && B < (1 << 19);
+    const bool dedup = !use_grid && pl.nsb <= 0xfff && B < (1 << 19);
     if (dedup) {
         hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.zrep, B, N);
         MMK_LAUNCH_CHECK();

@@ -1153,21 +1153,11 @@ int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
     return MMK_ERR_ARG;
 }
 
-bool use_ring_kernels()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MMK_CONV_RING");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 // the layers whose producing kernel can write the 2x2 max-pool of its output as well
 bool pool_fusable(int cin, int cout, int B, int H, int W)
 {
     const bool fits32 = (size_t)B * H * W * (size_t)std::max(cin, cout) < ((size_t)1 << 31);
-    return cin == cout && (cin == 16 || cin == 32) && fits32 && use_ring_kernels() && H >= 2 && W >= 2;
+    return cin == cout && (cin == 16 || cin == 32) && fits32 && H >= 2 && W >= 2;
 }
 
 int dispatch_conv(const ConvArgs &a, hipStream_t st)
@@ -1188,7 +1178,7 @@ int dispatch_conv(const ConvArgs &a, hipStream_t st)
         MMK_CONV_CASE(32, 16); MMK_CONV_CASE(32, 32);
 #undef MMK_CONV_CASE
     }
-    if (a.CIN == CK && CM <= 32 && fits32 && use_ring_kernels()) {
+    if (a.CIN == CK && CM <= 32 && fits32) {
 #define MMK_RING_CASE(K, M) if (CK == K && CM == M) return launch_conv_ring_epi<K, M>(a, st)
         MMK_RING_CASE(8, 16); MMK_RING_CASE(8, 32); MMK_RING_CASE(16, 16); MMK_RING_CASE(16, 32);
         MMK_RING_CASE(32, 16); MMK_RING_CASE(32, 32);
@@ -2013,17 +2003,7 @@ int wgrad_deep_slices(int cout, int cin, int B, int H, int W)
     return spatial >= 8 ? (spatial & ~7) : spatial;   // multiple of 8: XCD-contiguous tile walk
 }
 
-bool use_wgrad_deep()
-{
-    static int deep = -1;
-    if (deep < 0) {
-        const char *e = getenv("MMK_WGRAD_DEEP");
-        deep = (e && e[0] == '0') ? 0 : 1;
-    }
-    return deep == 1;
-}
-
-bool wgrad_is_deep(int cout, int cin, int c1) { return use_wgrad_deep() && cin % 64 == 0 && cout % 64 == 0 && c1 % 64 == 0; }
+bool wgrad_is_deep(int cout, int cin, int c1) { return cin % 64 == 0 && cout % 64 == 0 && c1 % 64 == 0; }
 
 int launch_wgrad_deep(const WgradArgs &a, hipStream_t st)
 {

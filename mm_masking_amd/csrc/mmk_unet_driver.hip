@@ -411,10 +411,9 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     };
     bool part_used[NCONV] = {};
     // 8 -> 8 and 16 -> 16 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the
-    // caller's stream -- both read the block's activation and the output gradient (MMK_UNET_BWD_FUSED=0: two launches)
-    static const bool fuse_env = !(getenv("MMK_UNET_BWD_FUSED") && getenv("MMK_UNET_BWD_FUSED")[0] == '0');
+    // caller's stream -- both read the block's activation and the output gradient
     auto can_fuse = [&](int k, int ch, int h, int w) {
-        return fuse_env && (ch == 8 || ch == 16) && sl == 0.f && p.slices[k] > 0 && mmk_conv3x3_wgrad_slices(ch, ch, ch, B, h, w) == p.slices[k];
+        return (ch == 8 || ch == 16) && sl == 0.f && p.slices[k] > 0 && mmk_conv3x3_wgrad_slices(ch, ch, ch, B, h, w) == p.slices[k];
     };
     auto bwd_fused = [&](int k, int ch, const void *x, const void *g, void *dx, int h, int w) -> int {
         const int rc = mmk_conv_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, ch, dx, static_cast<float *>(at(sc, p.part[k])),
@@ -465,7 +464,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             c.src1 = at(ws, p.a2[j].off); c.scale1 = 1.f;
             MMK_TRY(conv(p, h, w, sl, c, stream));
         }
-        if (j == 4 && fuse_env && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 8, B, h, w) == p.slices[k0]) {
+        if (j == 4 && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 8, B, h, w) == p.slices[k0]) {
             // last decoder block: both halves of the data gradient are masked by the two halves of the weight gradient's input
             MMK_TRY(mmk_conv16x8_bwd_fused(skip, at(ws, p.d1[j].off), at(sc, p.gz_a2[j].off), at(sc, p.packs_t[k0]), s, B, h, w,
                                            at(sc, p.gsk[j].off), at(sc, p.gz_d1[j].off), static_cast<float *>(at(sc, p.part[k0])),
@@ -490,7 +489,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             c3.src1 = at(ws, p.a1[j].off); c3.scale1 = 1.f;
             MMK_TRY(conv(p, h, w, sl, c3, stream));
         }
-        if (j == 4 && fuse_env && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 16, B, h, w) == p.slices[k0]) {
+        if (j == 4 && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 16, B, h, w) == p.slices[k0]) {
             // (first application: the input is the up-sampled tensor, no ReLU source -- the launch shares the output gradient)
             MMK_TRY(mmk_conv16x8_bwd_fused(at(ws, p.u[j].off), nullptr, at(sc, p.gz_a1[j].off), at(sc, p.packs_t[k0]), 1.f, B, h, w,
                                            at(sc, p.g_u[j].off), nullptr, static_cast<float *>(at(sc, p.part[k0])),
@@ -514,8 +513,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     }
     // the decoder's weight gradients are all enqueued: their slices are reduced under the >= 64-channel encoder levels, which
     // leave the HBM idle
-    static const bool split3 = !(getenv("MMK_UNPACK_SPLIT") && getenv("MMK_UNPACK_SPLIT")[0] == '0');
-    if (split3) MMK_TRY(unpack(12, 21));
+    MMK_TRY(unpack(12, 21));
     // ---- encoder, i = 5..1 (g_t = gradient w.r.t. t[i])
     const void *g_t = gz;
     for (int i = 5; i >= 1; --i) {
@@ -532,7 +530,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         }
         // data gradient accumulates into the skip gradient the decoder wrote for t[i-1]
         void *tgt = at(sc, p.gsk[5 - i].off);             // g_skip[i-1] was written by decoder block j = 4 - (i-1)
-        if (i == 1 && fuse_env && sl == 0.f && ch == 16 && ENC_CH[0] == 8 && p.slices[2] > 0 &&
+        if (i == 1 && sl == 0.f && ch == 16 && ENC_CH[0] == 8 && p.slices[2] > 0 &&
             mmk_conv3x3_wgrad_slices(16, 8, 8, B, h, w) == p.slices[2]) {
             // first convolution of block 1: weight gradient and (ReLU-masked, accumulating) data gradient in one launch
             MMK_TRY(mmk_conv8x16_bwd_fused(at(ws, p.t[0].off), at(sc, p.gz_a[1].off), at(sc, p.packs_t[2]), s, B, h, w, tgt,
@@ -550,8 +548,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         // the >= 64-channel encoder layers have their weight gradients enqueued: reduce their slices now (the reduction reads
         // every partial slice; as one launch at the end it is the tail of the backward pass, and beside the 640 x 640 kernels
         // it competes for their HBM bandwidth)
-        if (i == 3 && split3) MMK_TRY(unpack(6, 11));
-        if (i == 2 && !split3) MMK_TRY(unpack(4, 21));
+        if (i == 3) MMK_TRY(unpack(6, 11));
     }
     // ---- encoder block 0
     if (can_fuse(1, 8, p.H, p.W)) {
@@ -565,7 +562,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     }
     // ---- parameter gradients of the first five 3x3 layers (the rest was reduced on the way): on the weight-gradient stream,
     // beside the first layer's weight gradient
-    MMK_TRY(unpack(1, split3 ? 5 : 3));
+    MMK_TRY(unpack(1, 5));
     MMK_TRY(mmk_conv_first_wgrad(d->x, p.cin, at(sc, p.gz_a[0].off), d->pre, B, p.H, p.W, grads[0], grads[1],
                                  static_cast<float *>(at(sc, p.first_ws)), mmk_conv_first_wgrad_ws_bytes(p.cin), stream));
     if (ss) {       // join: the caller's stream continues only after every gradient is written
