@@ -419,7 +419,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &x1, __bf16 &x2, __bf16 &
 }
 
 template <int DIM>
-__global__ __launch_bounds__(NN_THREADS) void nn_mfma_kernel(
+__global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
     const float *__restrict__ src, const float *__restrict__ tgtp,
     const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx,
     const int32_t *__restrict__ ulist, const int32_t *__restrict__ ucnt, int ucap, int B,
@@ -543,36 +543,42 @@ __global__ __launch_bounds__(NN_THREADS) void nn_mfma_kernel(
             for (int g = 0; g < NNM_GROUPS; ++g) w[g] = 0u;
             // (tried, no gain: a software pipeline one chunk deep -- the MFMAs of chunk c + 1 issued between the reductions of
             // chunk c, pinned with sched_group_barrier: 173-199 VGPRs, two waves per SIMD instead of three, 20 % slower)
-            auto reduce = [&](const nn_f32x16 &acc, int g) {
-                // t = min(thr, chunk minimum): the chain starts from thr (a canonical fp32 value, so that no input of the
-                // v_min3 chain needs quieting), the chunk is flagged when t < thr, and min(brun, t) is the new bound either way
-                // (a tree, depth 3: a chain of 8 dependent v_min3 is latency-bound with 2-3 waves per SIMD)
+            // t = min(thr, chunk minimum) by a tree of v_min3 that starts from thr (a canonical fp32 value, so that no input of the
+            // tree needs quieting); the chunk is flagged when t < thr -- the sign bit of t - thr, shifted into the flag word by one
+            // v_alignbit (a compare + select through a lane mask costs 3 ns per MFMA more: scripts/ubench/mfma_valu.hip) -- and
+            // min(brun, t) is the new bound either way.  The threshold follows the bound every OTHER chunk: a stale threshold is
+            // a larger one (thr is monotone in the bound), which flags a superset, and the fma is one vector instruction less
+            // per MFMA on a loop the vector pipe binds (the matrix pipe does NOT hide it: 17.7 ns per MFMA and SIMD alone,
+            // 28.8 with the eight v_min3, 36.4 / 30.9 with the bookkeeping before / after this change).
+            auto reduce = [&](const nn_f32x16 &acc, int g, bool refresh) {
                 auto m3 = [](float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); };
                 const float m0 = m3(thr[g], acc[0], acc[1]), m1 = m3(acc[2], acc[3], acc[4]), m2 = m3(acc[5], acc[6], acc[7]);
                 const float m4 = m3(acc[8], acc[9], acc[10]), m5 = m3(acc[11], acc[12], acc[13]);
                 const float n0 = m3(m0, m1, m2), n1 = m3(m4, m5, acc[14]);
                 const float t = m3(n0, n1, acc[15]);
-                w[g] = (w[g] << 1) | ((t < thr[g]) ? 1u : 0u);         // chunk c ends up in bit 31 - c
+                w[g] = __builtin_amdgcn_alignbit(w[g], __float_as_uint(t - thr[g]), 31);      // chunk c ends up in bit 31 - c
                 brun[g] = __builtin_fminf(brun[g], t);
-                thr[g] = __builtin_fmaf(brun[g], kp1, c2[g]);
+                if (refresh) thr[g] = __builtin_fmaf(brun[g], kp1, c2[g]);
             };
             uint4 af_next = frag[0][lane];
 #pragma unroll 2
             for (int c = 0; c < NN_TILE / 32; ++c) {
                 const nn_bf16x8 af = __builtin_bit_cast(nn_bf16x8, af_next);
                 af_next = frag[(c + 1) & (NN_TILE / 32 - 1)][lane];          // next chunk's fragment in flight behind this chunk's MFMAs
-                nn_f32x16 acc[NNM_GROUPS];
+                const bool refresh = (c & 1) != 0;
+                // Two MFMAs in flight per wave (32 accumulator registers: 4 waves per SIMD).  MFMA g + 1 enters the matrix pipe
+                // when MFMA g leaves it, so the first result of a pair is complete 4 wait states behind the second issue; the second
+                // result is read behind the first reduction (12 vector instructions >= the 11 wait states of an 8-pass MFMA), which
+                // the second asm statement is tied to through that reduction's outputs.
 #pragma unroll
-                for (int g = 0; g < NNM_GROUPS; ++g) acc[g] = mfma_32x32x16_bf16_c0(af, bfr[g]);
-                // MFMA g + 1 enters the matrix pipe when MFMA g leaves it, so results 0..2 are complete 4 wait states behind
-                // the last issue; result 3 is read behind the three reductions (~40 vector instructions), which the second
-                // statement is tied to through their outputs
-                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
-                reduce(acc[0], 0);
-                reduce(acc[1], 1);
-                reduce(acc[2], 2);
-                asm volatile("" : "+v"(acc[3]), "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]));
-                reduce(acc[3], 3);
+                for (int h2 = 0; h2 < NNM_GROUPS; h2 += 2) {
+                    nn_f32x16 acc0 = mfma_32x32x16_bf16_c0(af, bfr[h2]);
+                    nn_f32x16 acc1 = mfma_32x32x16_bf16_c0(af, bfr[h2 + 1]);
+                    asm volatile("s_nop 3" : "+v"(acc0));
+                    reduce(acc0, h2, refresh);
+                    asm volatile("" : "+v"(acc1), "+v"(brun[h2]), "+v"(w[h2]));
+                    reduce(acc1, h2 + 1, refresh);
+                }
             }
             // ---- flags of the two lanes that share a point, then the exact re-scan of this tile's flagged chunks while
             // the tile is in LDS (chunks ascending, tiles ascending, strict '<': the lowest index among equal distances)
@@ -1440,8 +1446,8 @@ NNPlan nn_plan(int B, int N, int M, int dim)
     pl.total_units = Bpad * pl.nsb * pl.ntu;
     pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
     // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs); 3 of the matrix-core
-    // kernel's (40 KB of LDS each, <= 168 VGPRs)
-    pl.grid = std::min(pl.total_units, pl.mfma ? 768 : 2048);
+    // kernel's (40 KB of LDS each, <= 128 VGPRs)
+    pl.grid = std::min(pl.total_units, pl.mfma ? 1024 : 2048);
     return pl;
 }
 
