@@ -462,7 +462,8 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
         const float *tb = tgtp + (size_t)b * DIM * Mpad;
 
         // ---- the wave's 4 x 32 points: this lane's column of every group (both lanes l, l + 32 of a column do the same)
-        float p[NNM_GROUPS][DIM], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS];
+        float p[NNM_GROUPS][DIM], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
+        int jseed[NNM_GROUPS];
         nn_bf16x8 bfr[NNM_GROUPS];
         unsigned w[NNM_GROUPS];
 #pragma unroll
@@ -489,6 +490,8 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             bfr[g] = half ? hi : lo;
             // any e_j bounds the minimum: start from the previous iteration's correspondent (fp32 chain of the filter above)
             float b0 = INFINITY;
+            dseed[g] = INFINITY;
+            jseed[g] = -1;
             if (prev_idx != nullptr && i < N) {
                 const int j = prev_idx[(size_t)b * N + i];
                 if (j >= 0 && j < Mpad) {
@@ -496,20 +499,25 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                     const float jn = __builtin_fmaf(jy, jy, jx * jx);
                     b0 = __builtin_fmaf(jx, ax, __builtin_fmaf(jy, ay, jn));
                     b0 = (b0 == b0) ? b0 : INFINITY;
+                    const float dj = nn_dist<DIM>(jx, jy, 0.f, p[g]);       // the normative distance to the seed target
+                    dseed[g] = (dj == dj) ? dj : INFINITY;
+                    jseed[g] = j;
                 }
             }
             brun[g] = b0;
             thr[g] = __builtin_fmaf(b0, kp1, c2[g]);
         }
         // ---- the two points this lane owns for the exact part
-        float po[2][DIM], cur[2];
-        int pidx[2], jj[2];
+        float po[2][DIM], cur[2], dso[2];
+        int pidx[2], jj[2], jso[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
             for (int c = 0; c < DIM; ++c) po[q][c] = half ? p[2 + q][c] : p[q][c];
             pidx[q] = sb * NNM_PTS + wv * (NNM_GROUPS * 32) + (2 * half + q) * 32 + col;
             cur[q] = INFINITY;
+            dso[q] = half ? dseed[2 + q] : dseed[q];
+            jso[q] = half ? jseed[2 + q] : jseed[q];
         }
 
         const int t0 = tu * tiles_per_unit;
@@ -627,6 +635,11 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             const int i = pidx[q];
             if (i >= N) continue;
             if (!(cur[q] < INFINITY) && tu != 0) continue;
+            // A seeded point's answer is never farther than its seed target, whose own unit finds and writes it: a unit that
+            // holds neither the seed target nor anything as close has nothing to add to the atomic minimum ('<=': an equally
+            // distant target with a lower index must still get its say).  13.7 -> 1.5 MB of 8-byte atomics per launch.
+            const bool holds_seed = jso[q] >= t0 * NN_TILE && jso[q] < t1 * NN_TILE;
+            if (jso[q] >= 0 && !holds_seed && !(cur[q] <= dso[q])) continue;
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(cur[q]) << 32) | (unsigned long long)(unsigned)jj[q];
             atomicMin(&packed[(size_t)b * N + i], key);
@@ -1439,7 +1452,8 @@ NNPlan nn_plan(int B, int N, int M, int dim)
     // bound costs no atomic (5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch).  Matrix-core filter: a lane's
     // running bound restarts with every unit, and without a seed (the first ICP iteration) every restart flags a "record"
     // sequence of chunks that the exact part then re-scans: 324 / 170 us for the first / a later launch at 1 tile per unit,
-    // 265 / 162 at 2, 226 / 157 at 4.
+    // 265 / 162 at 2, 226 / 157 at 4 (round-3 build before the last tuning; the final kernel: 314 / 148 at 1 tile, 257 / 143 at 2,
+    // 195 / 133 at 4, 191 / 141 at 5, 210 / 163 at 10 -- each unit start costs two dependent gathers for the seed).
     pl.tiles_per_unit = std::min(pl.mfma ? 4 : 1, pl.ntiles);
     pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
