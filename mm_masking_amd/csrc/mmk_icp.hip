@@ -397,18 +397,13 @@ typedef __attribute__((ext_vector_type(16))) float nn_f32x16;
 constexpr int NNM_GROUPS = 4;                      // 32-point groups per wave
 constexpr int NNM_PTS = NN_THREADS / 64 * NNM_GROUPS * 32;    // 512 points per block
 
-// D = A B (C = 0) with the result in VGPRs, where the vector pipe consumes it at once (gfx950's register file is unified).
-// Inline asm on purpose: through the builtin hipcc either returns the tile in AGPRs (16 v_accvgpr_read per instruction) or,
-// with -amdgpu-mfma-vgpr-form, lets the destination overlap the dying A operand -- which a multi-pass MFMA must not do (its
-// later passes still read it): correspondences then changed from run to run (scripts/nn_determinism.py).  "=&v" forbids the
-// overlap.  hipcc pads nothing around asm (cdna_hip_programming.md §5.7), so the software wait between an MFMA and the
-// first vector read of its result is explicit too (passes + 3 = 11 wait states for this 8-pass instruction, 19 if it were a
-// 16-pass one): see the chunk loop.
+// D = A B (C = 0).  The compiler builtin, NOT inline asm: hipcc then keeps the result tile in VGPRs (gfx950's register file is
+// unified; the vector pipe consumes the tile at once) and pads the MFMA -> VALU read hazard itself (s_nop 8-10 behind each pair
+// of MFMAs; nothing is padded around asm statements).  Measured equal to a hand-scheduled asm form (134 us per launch either way).
 __device__ __forceinline__ nn_f32x16 mfma_32x32x16_bf16_c0(nn_bf16x8 a, nn_bf16x8 b)
 {
-    nn_f32x16 d;
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
-    return d;
+    const nn_f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
 }
 __device__ __forceinline__ void split3(float x, __bf16 &x1, __bf16 &x2, __bf16 &x3)
 {
@@ -462,7 +457,13 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
         const float *tb = tgtp + (size_t)b * DIM * Mpad;
 
         // ---- the wave's 4 x 32 points: this lane's column of every group (both lanes l, l + 32 of a column do the same)
-        float p[NNM_GROUPS][DIM], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
+        // Coordinates as separate scalars, selected with v_cndmask.  As an array p[g][c] handed to transform_point() and then
+        // read as `half ? p[2 + q] : p[q]` they became a 48-byte scratch-memory array read back at a run-time offset, and that
+        // round trip through scratch returned another unit's coordinates to 16 lanes of a wave now and then (one 64-byte
+        // sector; more often the slower the chunk loop was, and when the GPU was shared): correspondences that changed from
+        // run to run, and -- a NaN coordinate finds nothing -- keys that nobody armed.  Found with scripts/nn_sweep.py and
+        // scripts/nn_where.py; tests/test_round3_cpu.py now asserts that no kernel of the library uses scratch memory.
+        float px[NNM_GROUPS], py[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
         int jseed[NNM_GROUPS];
         nn_bf16x8 bfr[NNM_GROUPS];
         unsigned w[NNM_GROUPS];
@@ -477,10 +478,13 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                 s2 = sp[2];
             }
             const float s[3] = {s0, s1, s2};
-            transform_point<DIM>(T, s, p[g]);
-            const float pn = p[g][0] * p[g][0] + p[g][1] * p[g][1];
+            float tp[DIM];
+            transform_point<DIM>(T, s, tp);
+            px[g] = tp[0];
+            py[g] = tp[1];
+            const float pn = tp[0] * tp[0] + tp[1] * tp[1];
             c2[g] = 2.0f * kappa * pn + 1e-30f;
-            const float ax = -2.0f * p[g][0], ay = -2.0f * p[g][1];
+            const float ax = -2.0f * tp[0], ay = -2.0f * tp[1];
             __bf16 ax1, ax2, ax3, ay1, ay2, ay3;
             split3(ax, ax1, ax2, ax3);
             split3(ay, ay1, ay2, ay3);
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                     const float jn = __builtin_fmaf(jy, jy, jx * jx);
                     b0 = __builtin_fmaf(jx, ax, __builtin_fmaf(jy, ay, jn));
                     b0 = (b0 == b0) ? b0 : INFINITY;
-                    const float dj = nn_dist<DIM>(jx, jy, 0.f, p[g]);       // the normative distance to the seed target
+                    const float dj = nn_dist<DIM>(jx, jy, 0.f, tp);       // the normative distance to the seed target
                     dseed[g] = (dj == dj) ? dj : INFINITY;
                     jseed[g] = j;
                 }
@@ -508,12 +512,12 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             thr[g] = __builtin_fmaf(b0, kp1, c2[g]);
         }
         // ---- the two points this lane owns for the exact part
-        float po[2][DIM], cur[2], dso[2];
+        float pox[2], poy[2], cur[2], dso[2];
         int pidx[2], jj[2], jso[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) po[q][c] = half ? p[2 + q][c] : p[q][c];
+            pox[q] = half ? px[2 + q] : px[q];
+            poy[q] = half ? py[2 + q] : py[q];
             pidx[q] = sb * NNM_PTS + wv * (NNM_GROUPS * 32) + (2 * half + q) * 32 + col;
             cur[q] = INFINITY;
             dso[q] = half ? dseed[2 + q] : dseed[q];
@@ -574,17 +578,12 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                 const nn_bf16x8 af = __builtin_bit_cast(nn_bf16x8, af_next);
                 af_next = frag[(c + 1) & (NN_TILE / 32 - 1)][lane];          // next chunk's fragment in flight behind this chunk's MFMAs
                 const bool refresh = (c & 1) != 0;
-                // Two MFMAs in flight per wave (32 accumulator registers: 4 waves per SIMD).  MFMA g + 1 enters the matrix pipe
-                // when MFMA g leaves it, so the first result of a pair is complete 4 wait states behind the second issue; the second
-                // result is read behind the first reduction (12 vector instructions >= the 11 wait states of an 8-pass MFMA), which
-                // the second asm statement is tied to through that reduction's outputs.
+                // two MFMAs in flight per wave (32 accumulator registers: 4 waves per SIMD)
 #pragma unroll
                 for (int h2 = 0; h2 < NNM_GROUPS; h2 += 2) {
-                    nn_f32x16 acc0 = mfma_32x32x16_bf16_c0(af, bfr[h2]);
-                    nn_f32x16 acc1 = mfma_32x32x16_bf16_c0(af, bfr[h2 + 1]);
-                    asm volatile("s_nop 3" : "+v"(acc0));
+                    const nn_f32x16 acc0 = mfma_32x32x16_bf16_c0(af, bfr[h2]);
+                    const nn_f32x16 acc1 = mfma_32x32x16_bf16_c0(af, bfr[h2 + 1]);
                     reduce(acc0, h2, refresh);
-                    asm volatile("" : "+v"(acc1), "+v"(brun[h2]), "+v"(w[h2]));
                     reduce(acc1, h2 + 1, refresh);
                 }
             }
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                     const unsigned rest = ww & ~(0x80000000u >> c);
                     wo[0] = second ? wo[0] : rest;
                     wo[1] = second ? rest : wo[1];
-                    const float pq[DIM] = {second ? po[1][0] : po[0][0], second ? po[1][1] : po[0][1]};
+                    const float pq[DIM] = {second ? pox[1] : pox[0], second ? poy[1] : poy[0]};
                     const int o0 = c * 32;
                     float best = INFINITY;
                     int bj = 0;
@@ -640,6 +639,10 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             // distant target with a lower index must still get its say).  13.7 -> 1.5 MB of 8-byte atomics per launch.
             const bool holds_seed = jso[q] >= t0 * NN_TILE && jso[q] < t1 * NN_TILE;
             if (jso[q] >= 0 && !holds_seed && !(cur[q] <= dso[q])) continue;
+            if (holds_seed && !(cur[q] <= dso[q])) {       // (cannot happen while the filter holds; keeps the key armed whatever happens)
+                cur[q] = dso[q];
+                jj[q] = jso[q];
+            }
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(cur[q]) << 32) | (unsigned long long)(unsigned)jj[q];
             atomicMin(&packed[(size_t)b * N + i], key);
@@ -935,7 +938,8 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
         if (allzero != nullptr && allzero[(size_t)b * nn_nsb + i / nn_pts] != 0 && zrep[b] < (i / nn_pts) * nn_pts) isrc = zrep[b];
         const unsigned long long key = packed[(size_t)b * N + isrc];
         packed_next[(size_t)b * N + i] = NN_KEY_INIT;
-        const int j = (int)(unsigned)(key & 0xffffffffull);
+        // (an index outside the target can only come from a key nobody armed; it must not become an address)
+        const int j = min(max((int)(unsigned)(key & 0xffffffffull), 0), M - 1);
         idx_out[(size_t)b * N + i] = j;
         const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
         PointTerms<DIM, TYPE> t;
@@ -979,10 +983,13 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Small dense fp64 helpers (one lane).
+// (the callers keep A, rhs, x and the work space `ws` (P * P + P doubles) in LDS: as per-lane arrays with run-time indices
+// they would live in scratch memory, which this library does not use anywhere -- see nn_mfma_kernel)
 template <int P>
-__device__ bool chol_solve(const double *A /*P*P row-major symmetric*/, const double *rhs, double *x)
+__device__ bool chol_solve(const double *A /*P*P row-major symmetric*/, const double *rhs, double *x, double *ws)
 {
-    double L[P][P];
+    double (*L)[P] = reinterpret_cast<double (*)[P]>(ws);
+    double *y = ws + P * P;
     bool ok = true;
     for (int i = 0; i < P; ++i)
         for (int j = 0; j < P; ++j) {
@@ -1008,7 +1015,6 @@ __device__ bool chol_solve(const double *A /*P*P row-major symmetric*/, const do
         for (int i = 0; i < P; ++i) x[i] = 0.0;
         return false;
     }
-    double y[P];
     for (int i = 0; i < P; ++i) {
         double v = rhs[i];
         for (int q = 0; q < i; ++q) v -= L[i][q] * y[q];
@@ -1110,7 +1116,8 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
     }
     __syncthreads();
     if (lane != 0) return;
-    double A[P * P], rhs[P], dl[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ double A[P * P], rhs[P], dl[6], E[16], ws[P * P + P];
+    for (int q = 0; q < 6; ++q) dl[q] = 0.0;
     int a = 0;
     for (int m = 0; m < P; ++m)
         for (int n = m; n < P; ++n) {
@@ -1120,14 +1127,13 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
         }
     for (int m = 0; m < P; ++m) rhs[m] = acc[a++];
     for (int q = 0; q < 36; ++q) A_out[(size_t)b * 36 + q] = (q < P * P) ? A[q] : 0.0;
-    if (act) chol_solve<P>(A, rhs, dl);
+    if (act) chol_solve<P>(A, rhs, dl, ws);
     for (int q = 0; q < 6; ++q) delta_out[(size_t)b * 6 + q] = dl[q];
     if (!act) {
         for (int q = 0; q < 16; ++q) T_out[(size_t)b * 16 + q] = T_in[(size_t)b * 16 + q];
         active_out[b] = 0;
         return;
     }
-    double E[16];
     se_exp<DIM>(dl, E);
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -1252,7 +1258,7 @@ __global__ __launch_bounds__(64) void icp_bwd_pair_kernel(
     }
     if (lane == 0) {
         auto xb = [&](int r, int c) { return cur[r * 8 + 4 + c]; };
-        double db[P];
+        __shared__ double db[P], A[P * P], lam[P], ws[P * P + P];
         if (DIM == 2) {
             db[0] = xb(0, 3);
             db[1] = xb(1, 3);
@@ -1265,10 +1271,9 @@ __global__ __launch_bounds__(64) void icp_bwd_pair_kernel(
             db[P - 2] = xb(0, 2) - xb(2, 0);
             db[P - 1] = xb(1, 0) - xb(0, 1);
         }
-        double A[P * P], lam[P];
         for (int q = 0; q < P * P; ++q) A[q] = Amat[(size_t)b * 36 + q];
         // forward took delta = 0 when A was not positive definite: no dependence then
-        chol_solve<P>(A, db, lam);
+        chol_solve<P>(A, db, lam, ws);
         for (int q = 0; q < 6; ++q) lam_out[(size_t)b * 6 + q] = (q < P) ? lam[q] : 0.0;
     }
 }
