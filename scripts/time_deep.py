@@ -20,6 +20,6 @@ for H, cin, co in [(40, 128, 128), (40, 128, 256), (40, 256, 256), (40, 256, 128
     wp = uh.pack_weights(w)
     y = torch.empty(B, H, H, co, dtype=torch.bfloat16, device=DEV)
     bias = torch.zeros(co, device=DEV)
-    t = timeit(lambda: uh.conv3x3(x, wp, co, bias=bias, relu=True, drop_p=0.05, seed=3, out=y))
+    t = timeit(lambda: uh.conv3x3(x, wp, co, bias=bias, relu=True, drop_p=float(os.environ.get("DROP", "0.05")), seed=3, out=y))
     res.append("%d:%d>%d %.1f us %.0f TF/s" % (H, cin, co, t, 2.0 * 9 * cin * co * H * H * B / t * 1e-6))
 print(os.path.basename(os.environ.get("MMK_LIB", "default")), "|", " | ".join(res))
