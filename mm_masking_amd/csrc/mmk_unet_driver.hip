@@ -144,7 +144,9 @@ bool make_plan(Plan &p, int B, int H, int W, int cin, bool with_scratch)
     }
     for (int k = 1; k <= 21; ++k) {
         if (p.slices[k] <= 0) return false;      // every layer shape of the network has a partial-sum weight-gradient kernel
-        p.part[k] = s.take((size_t)p.slices[k] * ((size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k]) * 4);
+        // (a decoder convolution is applied twice per pass: each application writes slices of its own -- accumulating into
+        // the first application's slices was a read-modify-write of up to 38 MB at the tail of the kernel, +36 us per launch)
+        p.part[k] = s.take((size_t)(k >= 12 ? 2 : 1) * p.slices[k] * ((size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k]) * 4);
     }
     p.fin_ws = s.take((size_t)B * 130 * 4);
     p.fin_red = s.take((size_t)MMK_FINAL_BWD_WS_FLOATS * 4);
@@ -391,6 +393,13 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_CHECK_HIP(hipEventRecord(ss->fork, st));
         MMK_CHECK_HIP(hipStreamWaitEvent(ss->st, ss->fork, 0));
     }
+    int part_used[NCONV] = {};      // sets of partial slices layer k has written so far (decoder layers: one per application)
+    auto part_ptr = [&](int k) {
+        float *ptr = static_cast<float *>(at(sc, p.part[k])) +
+                     (size_t)part_used[k] * p.slices[k] * ((size_t)9 * p.cout[k] * p.cinn[k] + p.cout[k]);
+        part_used[k] += 1;
+        return ptr;
+    };
     // parameter gradients of layers k0..k1: sum the slices / transpose, one launch on the weight-gradient stream, behind the
     // weight-gradient launches enqueued so far
     auto unpack = [&](int k0, int k1) -> int {
@@ -404,22 +413,23 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         int n = 0;
         for (int k = k0; k <= k1; ++k, ++n) {
             src[n] = static_cast<const float *>(at(sc, p.part[k]));
-            slices[n] = p.slices[k]; co[n] = p.cout[k]; ci[n] = p.cinn[k];
+            if (part_used[k] != (k >= 12 ? 2 : 1)) {
+                mmk::set_error("mmk_unet_backward: layer %d wrote %d sets of partial slices", k, part_used[k]);
+                return MMK_ERR_ARG;
+            }
+            slices[n] = p.slices[k] * part_used[k]; co[n] = p.cout[k]; ci[n] = p.cinn[k];
             dW[n] = grads[2 * k]; db[n] = grads[2 * k + 1];
         }
         return mmk_conv3x3_wgrad_unpack_batch(n, src, slices, co, ci, dW, db, wstream);
     };
-    bool part_used[NCONV] = {};
+
     // 8 -> 8 and 16 -> 16 second convolutions (ReLU network): data gradient and partial weight gradient in one launch on the
     // caller's stream -- both read the block's activation and the output gradient
     auto can_fuse = [&](int k, int ch, int h, int w) {
         return (ch == 8 || ch == 16) && sl == 0.f && p.slices[k] > 0 && mmk_conv3x3_wgrad_slices(ch, ch, ch, B, h, w) == p.slices[k];
     };
     auto bwd_fused = [&](int k, int ch, const void *x, const void *g, void *dx, int h, int w) -> int {
-        const int rc = mmk_conv_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, ch, dx, static_cast<float *>(at(sc, p.part[k])),
-                                          part_used[k] ? 1 : 0, stream);
-        part_used[k] = true;
-        return rc;
+        return mmk_conv_bwd_fused(x, g, at(sc, p.packs_t[k]), 1.f, B, h, w, ch, dx, part_ptr(k), 0, stream);
     };
     auto wgrad = [&](int k, const void *x1, int C1, const void *x2, int C2, const void *g, int h, int w) -> int {
         if (ss) {   // g was produced by the launch just enqueued on the caller's stream
@@ -431,10 +441,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             mmk::set_error("mmk_unet_backward: partial-slice count of layer %d depends on the input split", k);
             return MMK_ERR_ARG;
         }
-        const int rc = mmk_conv3x3_wgrad_partial(x1, x2, C1, C2, g, p.cout[k], B, h, w, static_cast<float *>(at(sc, p.part[k])),
-                                                 part_used[k] ? 1 : 0, wstream);
-        part_used[k] = true;
-        return rc;
+        return mmk_conv3x3_wgrad_partial(x1, x2, C1, C2, g, p.cout[k], B, h, w, part_ptr(k), 0, wstream);
     };
 
     // ---- final layer
@@ -467,9 +474,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         if (j == 4 && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 8, B, h, w) == p.slices[k0]) {
             // last decoder block: both halves of the data gradient are masked by the two halves of the weight gradient's input
             MMK_TRY(mmk_conv16x8_bwd_fused(skip, at(ws, p.d1[j].off), at(sc, p.gz_a2[j].off), at(sc, p.packs_t[k0]), s, B, h, w,
-                                           at(sc, p.gsk[j].off), at(sc, p.gz_d1[j].off), static_cast<float *>(at(sc, p.part[k0])),
-                                           part_used[k0] ? 1 : 0, stream));
-            part_used[k0] = true;
+                                           at(sc, p.gsk[j].off), at(sc, p.gz_d1[j].off), part_ptr(k0), 0, stream));
         } else {
             MMK_TRY(wgrad(k0, skip, cs, at(ws, p.d1[j].off), cs, at(sc, p.gz_a2[j].off), h, w));
             ConvCall c2;       // one pass, two outputs: the skip's gradient and the first application's output gradient
@@ -492,9 +497,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         if (j == 4 && sl == 0.f && cs == 8 && p.slices[k0] > 0 && mmk_conv3x3_wgrad_slices(8, 16, 16, B, h, w) == p.slices[k0]) {
             // (first application: the input is the up-sampled tensor, no ReLU source -- the launch shares the output gradient)
             MMK_TRY(mmk_conv16x8_bwd_fused(at(ws, p.u[j].off), nullptr, at(sc, p.gz_a1[j].off), at(sc, p.packs_t[k0]), 1.f, B, h, w,
-                                           at(sc, p.g_u[j].off), nullptr, static_cast<float *>(at(sc, p.part[k0])),
-                                           part_used[k0] ? 1 : 0, stream));
-            part_used[k0] = true;
+                                           at(sc, p.g_u[j].off), nullptr, part_ptr(k0), 0, stream));
         } else {
             MMK_TRY(wgrad(k0, at(ws, p.u[j].off), 2 * cs, nullptr, 0, at(sc, p.gz_a1[j].off), h, w));
             ConvCall c4;
@@ -534,8 +537,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
             mmk_conv3x3_wgrad_slices(16, 8, 8, B, h, w) == p.slices[2]) {
             // first convolution of block 1: weight gradient and (ReLU-masked, accumulating) data gradient in one launch
             MMK_TRY(mmk_conv8x16_bwd_fused(at(ws, p.t[0].off), at(sc, p.gz_a[1].off), at(sc, p.packs_t[2]), s, B, h, w, tgt,
-                                           static_cast<float *>(at(sc, p.part[2])), part_used[2] ? 1 : 0, stream));
-            part_used[2] = true;
+                                           part_ptr(2), 0, stream));
         } else {
             MMK_TRY(wgrad(2 * i, at(ws, p.t[i - 1].off), ENC_CH[i - 1], nullptr, 0, at(sc, p.gz_a[i].off), h, w));
             ConvCall c2;

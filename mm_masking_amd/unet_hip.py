@@ -430,16 +430,21 @@ class _UNet(torch.autograd.Function):
         dB = {k: seg(2 * k + 1) for k in range(1, 22)}
 
         part = {}        # layer -> partial-sum slices (weights + bias)
+        part_sets = {}   # layer -> sets of slices written so far
 
         def wgrad(k, x1, g, x2=None):
             cout_k, cin_k = W(k).shape[0], W(k).shape[1]
             ns = wgrad_slices(cout_k, cin_k, x1.shape[3], x1.shape[0], x1.shape[1], x1.shape[2])
             if ns <= 0:
                 raise _lib.MmkError("U-Net backward: no weight-gradient kernel for %d -> %d channels" % (cin_k, cout_k))
-            first = k not in part
-            if first:
-                part[k] = partial_buffer(ns, cout_k, cin_k, dev)
-            conv3x3_wgrad_partial(x1, g, cout_k, part[k], x2=x2, accumulate=not first)
+            # (a decoder convolution is applied twice: each application writes its own set of slices, second application
+            # first -- the order of the native driver)
+            if k not in part:
+                part[k] = partial_buffer(ns * (2 if k >= 12 else 1), cout_k, cin_k, dev)
+                part_sets[k] = 0
+            u = part_sets[k]
+            part_sets[k] = u + 1
+            conv3x3_wgrad_partial(x1, g, cout_k, part[k][u * ns:(u + 1) * ns], x2=x2)
 
         # ---- final layer
         u4, a1_4, d1_4, a2_4, d2_4 = ctx.saved_dec[4]
@@ -516,6 +521,7 @@ class _UNet(torch.autograd.Function):
         conv_first_wgrad(x, gz_a0, ctx.pre, g_w0, g_b0)
         # ---- assemble parameter gradients in input order
         out = [g_w0, g_b0]
+        assert all(part_sets[k] == (2 if k >= 12 else 1) for k in range(1, 22))
         items = [(part[k], W(k).shape[0], W(k).shape[1], dB[k]) for k in range(1, 22)]
         for k, gw in zip(range(1, 22), wgrad_unpack_batch(items)):
             out += [gw, dB[k]]

@@ -161,7 +161,7 @@ class _UNetBN(torch.autograd.Function):
             ws += [bp(k)[0], bp(k)[4]]
         packs_t = uh.pack_weights_batch(ws[1:], transposed=True)
         pkt = {i + 1: tt for i, tt in enumerate(packs_t)}
-        part = {}
+        part, part_sets = {}, {}
 
         def wgrad(ci, x1, g, x2=None):
             w = ws[ci]
@@ -169,10 +169,13 @@ class _UNetBN(torch.autograd.Function):
             ns = uh.wgrad_slices(cout_k, cin_k, x1.shape[3], x1.shape[0], x1.shape[1], x1.shape[2])
             if ns <= 0:
                 raise _lib.MmkError("U-Net backward: no weight-gradient kernel for %d -> %d channels" % (cin_k, cout_k))
-            first = ci not in part
-            if first:
-                part[ci] = uh.partial_buffer(ns, cout_k, cin_k, dev)
-            uh.conv3x3_wgrad_partial(x1, g, cout_k, part[ci], x2=x2, accumulate=not first)
+            # (a decoder convolution is applied twice: each application writes its own set of slices)
+            if ci not in part:
+                part[ci] = uh.partial_buffer(ns * (2 if ci >= 12 else 1), cout_k, cin_k, dev)
+                part_sets[ci] = 0
+            u = part_sets[ci]
+            part_sets[ci] = u + 1
+            uh.conv3x3_wgrad_partial(x1, g, cout_k, part[ci][u * ns:(u + 1) * ns], x2=x2)
 
         seen = set()
 
@@ -235,6 +238,7 @@ class _UNetBN(torch.autograd.Function):
             g_t = g_skip[i - 1]
         block_bwd(0, ("e", 0), g_t)
         # ---- conv weight / bias gradients of the 21 3x3 layers
+        assert all(part_sets[ci] == (2 if ci >= 12 else 1) for ci in range(1, 22))
         items, idxs = [], []
         for ci in range(1, 22):
             w = ws[ci]
