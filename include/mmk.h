@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 300 /* 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
+#define MMK_VERSION 301 /* 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -195,6 +195,16 @@ int mmk_sample_weights_bwd(const float *grad_weights /*B,N*/, const float *pc, i
  * for bit whatever the device's division rounds to. */
 int mmk_host_read_rows(const char *path, int64_t header_bytes, int32_t rows, int32_t row_bytes, int32_t col0,
                        int32_t ncols, int32_t roll, void *dst);
+/* The same for a list of jobs (typically every tensor of every item of a batch), spread over `threads` host threads
+ * that live for the duration of the call: one interpreter thread drives the whole loader (the reference's four worker
+ * processes, train_icp_weights.py:454-455, become four C threads).  Fails if any job fails (first message kept). */
+typedef struct mmk_read_job {
+    const char *path;
+    int64_t header_bytes;
+    int32_t rows, row_bytes, col0, ncols, roll, reserved;
+    void *dst;
+} mmk_read_job;
+int mmk_host_read_rows_batch(const mmk_read_job *jobs, int32_t n_jobs, int32_t threads);
 int mmk_u8_to_float(const void *in /*n bytes*/, const float *lut256, int64_t n, float *out, void *stream);
 
 /* Statistics extract_weights returns next to the weights (radar_utils.py:130-138) and the policy's

@@ -30,6 +30,13 @@ class MmkError(RuntimeError):
     pass
 
 
+class ReadJob(ctypes.Structure):
+    """mmk_read_job of include/mmk.h (one row-copy of the batched loader)."""
+    _fields_ = [("path", ctypes.c_char_p), ("header_bytes", ctypes.c_int64), ("rows", ctypes.c_int32),
+                ("row_bytes", ctypes.c_int32), ("col0", ctypes.c_int32), ("ncols", ctypes.c_int32), ("roll", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("dst", ctypes.c_void_p)]
+
+
 class IcpParams(ctypes.Structure):
     """mmk_icp_params of include/mmk.h."""
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("M", ctypes.c_int32),
@@ -158,6 +165,7 @@ def _declare(lib):
         "mmk_cart_to_polar": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, i32, ctypes.c_double, c_vp, c_vp]),
         "mmk_sample_weights_fwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_host_read_rows": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, i32, i32, i32, i32, i32, c_vp]),
+        "mmk_host_read_rows_batch": (ctypes.c_int, [ctypes.POINTER(ReadJob), i32, i32]),
         "mmk_u8_to_float": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
         "mmk_sample_weights_bwd_ws_bytes": (sz, [i32, i32]),
         "mmk_sample_weights_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, i32, i32, f32, c_vp, c_vp, sz, c_vp]),

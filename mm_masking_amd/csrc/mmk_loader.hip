@@ -12,6 +12,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "mmk_common.h"
@@ -75,6 +78,40 @@ extern "C" int mmk_host_read_rows(const char *path, int64_t header_bytes, int32_
     }
     close(fd);
     return rc;
+}
+
+// A whole batch in one call: the jobs (one per tensor and item) are drawn from a shared counter by `threads` host threads of
+// this call's own (created here, joined before returning: no pool, no state left behind).  The Python side then needs ONE
+// interpreter thread per loader instead of one per worker -- with eight Python worker threads the training thread's 2.5 ms of
+// enqueue work per step kept waiting for the interpreter lock and a loader-fed step ran 25 % below the step's own rate.
+extern "C" int mmk_host_read_rows_batch(const mmk_read_job *jobs, int32_t n_jobs, int32_t threads)
+{
+    MMK_REQUIRE(jobs && n_jobs >= 1, "mmk_host_read_rows_batch: no jobs");
+    const int nt = std::max(1, std::min<int>(threads, n_jobs));
+    std::atomic<int> next(0), failed(0);
+    std::string first_error;
+    std::atomic<bool> have_error(false);
+    auto work = [&]() {
+        for (int j = next.fetch_add(1); j < n_jobs; j = next.fetch_add(1)) {
+            const mmk_read_job &q = jobs[j];
+            const int rc = mmk_host_read_rows(q.path, q.header_bytes, q.rows, q.row_bytes, q.col0, q.ncols, q.roll, q.dst);
+            if (rc != MMK_OK) {
+                failed.fetch_add(1);
+                bool expect = false;
+                if (have_error.compare_exchange_strong(expect, true)) first_error = mmk_last_error();   // (the message is per thread)
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    if (failed.load() != 0) {
+        mmk::set_error("mmk_host_read_rows_batch: %d of %d jobs failed; first: %s", failed.load(), n_jobs, first_error.c_str());
+        return MMK_ERR_ARG;
+    }
+    return MMK_OK;
 }
 
 namespace {

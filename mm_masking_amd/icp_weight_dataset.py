@@ -363,60 +363,70 @@ class ICPWeightDataset(torch.utils.data.Dataset):
                 "map_data": {"pc": ((self.max_map_pts, 6), f), "timestamp": ((), torch.int64)},
                 "transforms": {"T_ml_init": ((4, 4), f), "T_ml_gt": ((4, 4), f)}}
 
-    def fill_item(self, index, bufs, j):
-        """Item ``index`` written into row ``j`` of the batch buffers ``bufs`` (native_item_spec's layout): the same item as
+    def fill_batch(self, indices, bufs, threads=4):
+        """Items ``indices`` written into rows 0.. of the batch buffers ``bufs`` (native_item_spec's layout): the same items as
         ``__getitem__`` of the ``batched_prepare`` mode, except that the augmentation's rotation of the clouds is left to the
-        device (``aug_cs`` = (cos, sin) of the drawn yaw; finish_batch applies it), and with every byte moved by
-        mmk_host_read_rows (one C call per tensor, GIL released) instead of numpy / torch copies.  The interpreter's share
-        is kept small on purpose (it is what the worker threads serialise on): paths and caches are resolved once per
-        sample, destinations are raw pointers, the 400 azimuths are handled in numpy."""
+        device (``aug_cs`` = (cos, sin) of the drawn yaw; finish_batch applies it).  ONE interpreter thread: the per-item share
+        that needs Python (paths and caches resolved once per sample, the 400 encoder counts -> azimuths in numpy, the
+        augmentation's yaw drawn in item order -- reproducible under a seed, which a pool of worker threads is not) runs
+        here; every byte of the tensors is then moved by one mmk_host_read_rows_batch call whose ``threads`` C threads share
+        the jobs (page cache -> pinned memory, column cut and azimuth roll on the way; GIL released for the whole batch)."""
         from . import _lib
-        rd = _lib.lib().mmk_host_read_rows
+        L = _lib.lib()
+        rd = L.mmk_host_read_rows
         loc, mp, tr = bufs["loc_data"], bufs["map_data"], bufs["transforms"]
-        info = self._native_info.get(index)
-        if info is None:
-            assert self.float_type == torch.float32, "native loader path: float32 items"
-            rpath, cpath = self.loc_radar_path_list[index], self.loc_cfar_path_list[index]
-            for png in (rpath, cpath):                 # the decoded-byte caches (written on first use)
-                if not os.path.exists(png + ".u8") or os.path.getmtime(png + ".u8") < os.path.getmtime(png):
-                    self._decoded(png)
-            info = ((rpath + ".u8").encode(), (cpath + ".u8").encode(), self._prepared_clouds(index).encode())
-            self._native_info[index] = info
-        rfile, cfile, prep = info
-        _, loc_stamp, map_stamp = self.samples[index]
         A, R = loc["fft_u8"].shape[1], loc["fft_u8"].shape[2]
-
-        def dst(t):
-            return t.data_ptr() + j * t.stride(0) * t.element_size()
-
-        def chk(rc):
-            if rc != 0:
-                raise _lib.MmkError(_lib.lib().mmk_last_error().decode())
-        enc = np.empty((A, 2), np.uint8)
-        chk(rd(rfile, 8, A, R + 11, 8, 2, 0, enc.ctypes.data))
-        # load_radar's azimuths (radar_utils.py:23-24): uint16 counts * (2 pi / 5600) in float64, then the Dataset's cast
-        az = (enc.view(np.uint16).reshape(A) * (2 * np.pi / 5600)).astype(np.float32)
-        shift, c, s = 0, 1.0, 0.0
-        if self.augment:                                # icp_weight_dataset.py:425-452
-            angle = 2 * np.pi * torch.rand(1, dtype=self.float_type)
-            c, s = float(torch.cos(angle)), float(torch.sin(angle))
-            az = az - np.float32(angle.item())          # fp32 arithmetic, as the tensor expression upstream
-            az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
-            shift = -int(np.argmin(az))
-            az = np.roll(az, shift)
-        loc["azimuths"].numpy()[j] = az
-        cs = loc["aug_cs"].numpy()
-        cs[j, 0], cs[j, 1] = c, s
-        chk(rd(rfile, 8, A, R + 11, 11, R, shift, dst(loc["fft_u8"])))
-        chk(rd(cfile, 8, A, R, 0, R, shift, dst(loc["cfar_u8"])))
         nb_scan, nb_map = self.max_loc_pts * 12, self.max_map_pts * 24
-        chk(rd(prep, 0, 1, nb_scan, 0, nb_scan, 0, dst(loc["raw_pc"])))
-        chk(rd(prep, nb_scan, 1, nb_scan, 0, nb_scan, 0, dst(loc["filtered_pc"])))
-        chk(rd(prep, 2 * nb_scan, 1, nb_map, 0, nb_map, 0, dst(mp["pc"])))
-        loc["timestamp"].numpy()[j] = loc_stamp
-        mp["timestamp"].numpy()[j] = map_stamp
-        tr["T_ml_init"].numpy()[j] = self.T_loc_init[index].numpy()
-        tr["T_ml_gt"].numpy()[j] = self.T_loc_gt[index].numpy()
+        jobs = (_lib.ReadJob * (5 * len(indices)))()
+        keep = []                                      # (the path bytes must outlive the call)
+        az_all, cs_all = loc["azimuths"].numpy(), loc["aug_cs"].numpy()
+        enc = np.empty((A, 2), np.uint8)
+        n = 0
+        for j, index in enumerate(indices):
+            info = self._native_info.get(index)
+            if info is None:
+                assert self.float_type == torch.float32, "native loader path: float32 items"
+                rpath, cpath = self.loc_radar_path_list[index], self.loc_cfar_path_list[index]
+                for png in (rpath, cpath):
+                    if not os.path.exists(png + ".u8") or os.path.getmtime(png + ".u8") < os.path.getmtime(png):
+                        self._decoded(png)
+                info = ((rpath + ".u8").encode(), (cpath + ".u8").encode(), self._prepared_clouds(index).encode())
+                self._native_info[index] = info
+            rfile, cfile, prep = info
+            keep.append(info)
+            if rd(rfile, 8, A, R + 11, 8, 2, 0, enc.ctypes.data) != 0:
+                raise _lib.MmkError(L.mmk_last_error().decode())
+            az = (enc.view(np.uint16).reshape(A) * (2 * np.pi / 5600)).astype(np.float32)
+            shift, c, s = 0, 1.0, 0.0
+            if self.augment:
+                angle = 2 * np.pi * torch.rand(1, dtype=self.float_type)
+                c, s = float(torch.cos(angle)), float(torch.sin(angle))
+                az = az - np.float32(angle.item())
+                az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
+                shift = -int(np.argmin(az))
+                az = np.roll(az, shift)
+            az_all[j] = az
+            cs_all[j, 0], cs_all[j, 1] = c, s
+
+            def dst(t):
+                return t.data_ptr() + j * t.stride(0) * t.element_size()
+            for (path, hdr, rows, rb, c0, nc, roll, d) in (
+                    (rfile, 8, A, R + 11, 11, R, shift, dst(loc["fft_u8"])),
+                    (cfile, 8, A, R, 0, R, shift, dst(loc["cfar_u8"])),
+                    (prep, 0, 1, nb_scan, 0, nb_scan, 0, dst(loc["raw_pc"])),
+                    (prep, nb_scan, 1, nb_scan, 0, nb_scan, 0, dst(loc["filtered_pc"])),
+                    (prep, 2 * nb_scan, 1, nb_map, 0, nb_map, 0, dst(mp["pc"]))):
+                q = jobs[n]
+                q.path, q.header_bytes, q.rows, q.row_bytes, q.col0, q.ncols, q.roll, q.dst = path, hdr, rows, rb, c0, nc, roll, d
+                n += 1
+            _, loc_stamp, map_stamp = self.samples[index]
+            loc["timestamp"].numpy()[j] = loc_stamp
+            mp["timestamp"].numpy()[j] = map_stamp
+            tr["T_ml_init"].numpy()[j] = self.T_loc_init[index].numpy()
+            tr["T_ml_gt"].numpy()[j] = self.T_loc_gt[index].numpy()
+        if L.mmk_host_read_rows_batch(jobs, n, int(threads)) != 0:
+            raise _lib.MmkError(L.mmk_last_error().decode())
+        del keep
 
     def get_item_from_loc_timestamp(self, loc_stamp_req):
         """icp_weight_dataset.py:454-495."""
@@ -502,11 +512,15 @@ class DeviceLoader:
     which the thread mode leaves to the device (tests/test_round3_cpu.py, tests/test_gpu_round3.py)."""
 
     def __init__(self, dataset, batch_size, device, num_workers=4, shuffle=False, drop_last=False, prefetch_factor=2,
-                 persistent_workers=True, mode="threads"):
+                 persistent_workers=True, mode="threads", passes=1):
         if not getattr(dataset, "batched_prepare", False):
             raise ValueError("DeviceLoader needs a Dataset built with params['batched_prepare'] = True (CPU-only items)")
         if mode not in ("threads", "processes"):
             raise ValueError("mode must be 'threads' or 'processes'")
+        if passes != 1 and (mode != "threads" or num_workers == 0):
+            raise ValueError("passes > 1 (several passes over the data in ONE iteration, the pipeline kept full across them) "
+                             "is a feature of the thread mode")
+        self.passes = int(passes)
         self.dataset, self.device, self.mode = dataset, torch.device(device), mode
         self.batch_size, self.shuffle, self.drop_last, self.num_workers = int(batch_size), shuffle, drop_last, int(num_workers)
         self.loader = None
@@ -517,22 +531,22 @@ class DeviceLoader:
             self.loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
                                                       drop_last=drop_last, pin_memory=self.device.type == "cuda", **kw)
         self._side = None
-        self._pool = None
         self._bufs = {}            # (slot, batch length) -> pinned batch buffers
 
     def __len__(self):
         n = len(self.dataset)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return self.passes * (n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size)
 
     # -- thread mode: items written in place into pinned batch buffers
     def _batches(self):
         n = len(self.dataset)
-        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
-        for i in range(0, n, self.batch_size):
-            idx = order[i:i + self.batch_size]
-            if len(idx) < self.batch_size and self.drop_last:
-                return
-            yield idx
+        for _ in range(self.passes):
+            order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+            for i in range(0, n, self.batch_size):
+                idx = order[i:i + self.batch_size]
+                if len(idx) < self.batch_size and self.drop_last:
+                    break
+                yield idx
 
     def _assemble(self, slot, idx):
         key = (slot, len(idx))
@@ -542,22 +556,21 @@ class DeviceLoader:
             bufs = {grp: {k: torch.empty((len(idx),) + tuple(shape), dtype=dt, pin_memory=pin and len(shape) > 0)
                           for k, (shape, dt) in d.items()} for grp, d in self.dataset.native_item_spec().items()}
             self._bufs[key] = bufs
-        list(self._pool.map(lambda a: self.dataset.fill_item(a[1], bufs, a[0]), enumerate(idx)))
+        # one interpreter thread, num_workers C threads (fill_batch); the Python worker pool of the first cut made the
+        # training thread wait for the interpreter lock
+        self.dataset.fill_batch(idx, bufs, threads=self.num_workers)
         return bufs
 
     N_SLOTS = 4          # pinned batch buffers: one being filled, up to two queued, one being copied to the device
 
     def _cpu_batches(self):
-        """Host batches, in order.  Thread mode: a producer thread assembles batch i + 1, i + 2 into free pinned slots (its
-        worker threads do the copying in C) while the caller's thread enqueues the step of batch i; ``_release`` hands a slot
-        back once the side stream has copied it to the device."""
+        """Host batches, in order.  Thread mode: ONE producer thread assembles batch i + 1, i + 2 into free pinned slots
+        (``fill_batch``: the copying is done by ``num_workers`` C threads inside one library call) while the caller's thread
+        enqueues the step of batch i; ``_release`` hands a slot back once the side stream has copied it to the device."""
         if self.loader is not None:
             yield from self.loader
             return
         import queue
-        from concurrent.futures import ThreadPoolExecutor
-        if self._pool is None:
-            self._pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="mmk-loader")
         q = queue.Queue(maxsize=2)
         self._free = threading.Semaphore(self.N_SLOTS)
         stop = threading.Event()

@@ -93,14 +93,20 @@ def test_loader_throughput_against_step_rate(tmp_path):
             loss, _ = trn.train_step(model, b, opt, lw, DEV)
     torch.cuda.synchronize()
     res["step_pairs_per_s_resident_batches"] = 5 * len(batches) * B / (time.time() - t0)
-    t0 = time.time()
-    cnt = 0
-    for ep in range(4):
+    # 16 passes over the 64 items in one iteration (32 batches, the pipeline stays full across the passes as it does over a
+    # real epoch; restarting the iterator every 2 batches would time the pipeline's fill, not its rate)
+    for nw in (4, 8):
+        dl = ds.DeviceLoader(d, batch_size=B, device=DEV, num_workers=nw, mode="threads", passes=16)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        cnt = 0
         for b in dl:
             loss, _ = trn.train_step(model, b, opt, lw, DEV)
             cnt += B
-    torch.cuda.synchronize()
-    res["train_pairs_per_s_fed_by_loader"] = cnt / (time.time() - t0)
+        torch.cuda.synchronize()
+        res["train_pairs_per_s_fed_by_loader_threads_%d" % nw] = cnt / (time.time() - t0)
+        del dl
+    res["train_pairs_per_s_fed_by_loader"] = res["train_pairs_per_s_fed_by_loader_threads_8"]
     assert torch.isfinite(loss)
     try:
         os.makedirs(OUT, exist_ok=True)

@@ -78,7 +78,7 @@ def test_worker_items_augmentation_matches_default_mode(golden_dir, tmp_path):
 
 
 def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path):
-    """DeviceLoader's thread mode: ``fill_item`` (every tensor moved by mmk_host_read_rows: column cut + azimuth roll in C,
+    """DeviceLoader's thread mode: ``fill_batch`` (every tensor moved by mmk_host_read_rows_batch: column cut + azimuth roll in C,
     clouds from the prepared-cloud cache) + ``finish_batch`` (rotation of the clouds on the device) against the default
     item mode under the same yaw draw: images, azimuths, poses, stamps bit-equal; rotated clouds to fp32 rounding."""
     g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
@@ -94,7 +94,7 @@ def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path
             torch.manual_seed(91 + i)
             a = torch.utils.data.default_collate([ref[i]])
             torch.manual_seed(91 + i)
-            wrk.fill_item(i, bufs, 0)
+            wrk.fill_batch([i], bufs, threads=2)
             b = ds.finish_batch(bufs, "cpu", network_input_type="polar")
             for key in ("fft_data", "fft_cfar", "timestamp"):
                 _same(a["loc_data"][key], b["loc_data"][key], key)
@@ -131,6 +131,18 @@ def test_host_read_rows_roll_and_columns(tmp_path):
     assert np.array_equal(full, img)
     assert L.mmk_host_read_rows(path.encode(), 8, 8, 23, 0, 23, 0, full.ctypes.data) != 0 and b"shorter" in L.mmk_last_error()
     assert L.mmk_host_read_rows(str(tmp_path / "missing").encode(), 0, 1, 4, 0, 4, 0, full.ctypes.data) != 0
+    # the batched form: 12 jobs on 3 threads, then one bad job among them
+    outs = [np.zeros((7, 10), np.uint8) for _ in range(12)]
+    jobs = (_lib.ReadJob * 12)()
+    pb = path.encode()
+    for k, o in enumerate(outs):
+        jobs[k].path, jobs[k].header_bytes, jobs[k].rows, jobs[k].row_bytes = pb, 8, 7, 23
+        jobs[k].col0, jobs[k].ncols, jobs[k].roll, jobs[k].dst = k, 10, k - 4, o.ctypes.data
+    _lib.check(L.mmk_host_read_rows_batch(jobs, 12, 3))
+    for k, o in enumerate(outs):
+        assert np.array_equal(o, np.roll(img[:, k:k + 10], k - 4, axis=0)), k
+    jobs[5].rows = 9
+    assert L.mmk_host_read_rows_batch(jobs, 12, 3) != 0 and b"1 of 12 jobs failed" in L.mmk_last_error()
 
 
 def _device_code_objects(so_path):
