@@ -458,11 +458,11 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
 
         // ---- the wave's 4 x 32 points: this lane's column of every group (both lanes l, l + 32 of a column do the same)
         // Coordinates as separate scalars, selected with v_cndmask.  As an array p[g][c] handed to transform_point() and then
-        // read as `half ? p[2 + q] : p[q]` they became a 48-byte scratch-memory array read back at a run-time offset, and that
-        // round trip through scratch returned another unit's coordinates to 16 lanes of a wave now and then (one 64-byte
-        // sector; more often the slower the chunk loop was, and when the GPU was shared): correspondences that changed from
-        // run to run, and -- a NaN coordinate finds nothing -- keys that nobody armed.  Found with scripts/nn_sweep.py and
-        // scripts/nn_where.py; tests/test_round3_cpu.py now asserts that no kernel of the library uses scratch memory.
+        // read as `half ? p[2 + q] : p[q]` they became a 48-byte scratch-memory array read back at a run-time offset; with that
+        // build 16-lane groups of a wave now and then worked on wrong coordinates (correspondences that changed from run to
+        // run; a NaN coordinate finds nothing, so keys that nobody armed).  The round trip is sound in isolation
+        // (scripts/ubench/scratch_roundtrip.hip); what failed in the full process is not established.  The
+        // library uses no scratch memory anywhere: tests/test_round3_cpu.py::test_no_kernel_uses_scratch_memory.
         float px[NNM_GROUPS], py[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
         int jseed[NNM_GROUPS];
         nn_bf16x8 bfr[NNM_GROUPS];
