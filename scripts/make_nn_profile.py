@@ -5,16 +5,22 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, out = sys.argv[1], sys.argv[2]
 valid = float(sys.argv[3]) if len(sys.argv) > 3 else 4300.0
-c = {}
-dur = []
+c, coarse = {}, {}
+dur, cdur = [], []
 for i in (1, 2, 3):
     d = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_nn_%s_%d.json" % (tag, i))))
-    k = [n for n in d if n.startswith("nn_")][0]
+    k = [n for n in d if n.startswith("nn_") and "coarse" not in n][0]          # the scan itself (nn_mfma_kernel / nn_prefilter_kernel)
     for name, v in d[k].items():
         if name == "duration_ns":
             dur.append(v["mean"])
         else:
             c[name] = v["mean"]
+    for kc in [n for n in d if "coarse" in n]:                                # the first iteration's seed pass (1 launch in 10)
+        for name, v in d[kc].items():
+            if name == "duration_ns":
+                cdur.append(v["mean"])
+            else:
+                coarse[name] = v["mean"]
 kern = k
 dur_ns = sum(dur) / len(dur)
 B, N, Mpad, dim = 32, 5120, 20480, 2
@@ -34,6 +40,10 @@ pmc = {"kernel": kern, "shape": "B=32, N=5120 padded (~%d valid rows per pair, z
        "note": "separate rocprofv3 --pmc passes (scripts/pmc_nn.sh; FETCH_SIZE and WRITE_SIZE in passes of their own). SQ_* cycle counters are "
                "quad-cycles summed over the waves; SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16. The LDS bank conflicts are "
                "the exact re-scan's per-lane reads of the fp32 planes (each lane its own chunk)."}
+if coarse:
+    pmc["coarse_seed_pass"] = {"kernel": "nn_coarse_seed_kernel<2>", "launches": "one per icp() call, in front of the first (unseeded) scan",
+                               "avg_launch_us": sum(cdur) / len(cdur) / 1e3, "counters_per_launch": coarse,
+                               "note": "4-byte gathers of every 64th target (FETCH_SIZE not doubled: narrow reads)"}
 json.dump(pmc, open(os.path.join(ROOT, "profiles", out + "_nn_pmc_counters.json"), "w"), indent=1)
 fetch, write = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
 tr = {"kernel": kern, "shape": pmc["shape"], "density": "survey (%d valid scan points per pair)" % valid, "avg_launch_us": round(dur_ns / 1e3, 1),
