@@ -58,8 +58,10 @@ __device__ __forceinline__ float nn_dist(float tx, float ty, float tz, const flo
 
 // ------------------------------------------------------------------------------------------
 // Planar, padded copy of the target coordinates: (B,M,cols) AoS -> (B,DIM,Mpad).
+// `dec` (optional, (B, dim, Mpad / dec_stride)): every dec_stride-th target again, densely -- the samples of the first
+// iteration's coarse seed pass (nn_coarse_seed_kernel), which would otherwise gather them 4 bytes at a time.
 __global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int cols, int dim, int Mpad,
-                                   float *__restrict__ out)
+                                   float *__restrict__ out, float *__restrict__ dec, int dec_stride)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int b = blockIdx.y;
@@ -68,6 +70,7 @@ __global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int col
         float v = NN_PAD;
         if (j < M) v = tgt[((size_t)b * M + j) * cols + c];
         out[((size_t)b * dim + c) * Mpad + j] = v;
+        if (dec != nullptr && j % dec_stride == 0) dec[((size_t)b * dim + c) * (Mpad / dec_stride) + j / dec_stride] = v;
     }
 }
 
@@ -664,7 +667,8 @@ template <int DIM>
 __global__ __launch_bounds__(NN_COARSE_THREADS) void nn_coarse_seed_kernel(const float *__restrict__ src, const float *__restrict__ tgtp,
                                                              const float *__restrict__ Tk, const int32_t *__restrict__ active,
                                                              const int32_t *__restrict__ allzero, const int32_t *__restrict__ zrep,
-                                                             int nn_pts, int nsb, int N, int Mpad, int32_t *__restrict__ seed)
+                                                             int nn_pts, int nsb, int N, int Mpad, const float *__restrict__ dec,
+                                                             int32_t *__restrict__ seed)
 {
     __shared__ __attribute__((aligned(16))) float st[DIM][NN_COARSE_TILE];
     const int b = blockIdx.y;
@@ -693,7 +697,9 @@ __global__ __launch_bounds__(NN_COARSE_THREADS) void nn_coarse_seed_kernel(const
         for (int q = threadIdx.x; q < NN_COARSE_TILE; q += NN_COARSE_THREADS) {
             const int sidx = s0 + q;
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) st[c][q] = sidx < ns ? tb[(size_t)c * Mpad + (size_t)sidx * NN_COARSE_STRIDE] : 3e18f;
+            for (int c = 0; c < DIM; ++c)
+                st[c][q] = sidx >= ns ? 3e18f
+                                      : (dec != nullptr ? dec[((size_t)b * DIM + c) * ns + sidx] : tb[(size_t)c * Mpad + (size_t)sidx * NN_COARSE_STRIDE]);
         }
         __syncthreads();
         const int cnt = min(NN_COARSE_TILE, ns - s0);
@@ -1559,7 +1565,8 @@ thread_local NNProf g_prof;      // per host thread: the library keeps no proces
 // `seed_buf` ((B,N) int32, may be null): where the coarse pass puts the seeds of a launch without previous correspondents.
 int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, const int32_t *active,
               const int32_t *prev_idx, const int32_t *ulist, const int32_t *ucnt, int B, int N, const NNPlan &pl,
-              unsigned long long *packed, int32_t *seed_buf, const int32_t *allzero, const int32_t *zrep, hipStream_t st)
+              unsigned long long *packed, int32_t *seed_buf, const int32_t *allzero, const int32_t *zrep, const float *dec,
+              hipStream_t st)
 {
     const bool rec = g_prof.on && g_prof.n < g_prof.cap;
     if (rec) MMK_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
@@ -1568,10 +1575,10 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
         const int nn_pts = NN_THREADS * pl.P;
         if (dim == 2)
             hipLaunchKernelGGL(nn_coarse_seed_kernel<2>, grid, dim3(NN_COARSE_THREADS), 0, st, src, tgtp, Tk, active, allzero, zrep, nn_pts, pl.nsb, N,
-                               pl.Mpad, seed_buf);
+                               pl.Mpad, dec, seed_buf);
         else
             hipLaunchKernelGGL(nn_coarse_seed_kernel<3>, grid, dim3(NN_COARSE_THREADS), 0, st, src, tgtp, Tk, active, allzero, zrep, nn_pts, pl.nsb, N,
-                               pl.Mpad, seed_buf);
+                               pl.Mpad, dec, seed_buf);
         MMK_LAUNCH_CHECK();
         prev_idx = seed_buf;
     }
@@ -1615,6 +1622,7 @@ struct IcpWs {
     int32_t *allzero, *zrep;     // (B,nsb), (B): zero-row bookkeeping of the source (src_zero_scan_kernel)
     int32_t *ulist, *ucnt;       // (8,ucap), (16): the source blocks the NN kernel scans (src_units_kernel)
     int32_t *seed0;              // (B,N): coarse seeds of the first iteration (nn_coarse_seed_kernel)
+    float *tdec;                 // (B,dim,Mpad/NN_COARSE_STRIDE): every 64th target, densely (its samples)
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
     double *lam;        // backward (B,6)
@@ -1637,6 +1645,7 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     w.ulist = ar.take<int32_t>((size_t)8 * pl.ucap);
     w.ucnt = ar.take<int32_t>(16);
     w.seed0 = ar.take<int32_t>((size_t)p->B * p->N);
+    w.tdec = ar.take<float>((size_t)p->B * p->dim * (pl.Mpad / NN_COARSE_STRIDE));
     w.partials = ar.take<double>((size_t)p->B * nblk * 27);
     w.G0 = ar.take<double>((size_t)p->B * 16);
     w.G1 = ar.take<double>((size_t)p->B * 16);
@@ -1707,7 +1716,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
         } else {
             // the correspondences of the previous iteration (still in the index buffer) start the filter's bound
             const int32_t *prev = (it > 0) ? idx_hist + (p->save_state ? (size_t)(it - 1) * B * N : 0) : nullptr;
-            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, prev, dedup ? w.ulist : nullptr, w.ucnt, B, N, pl, keys, w.seed0, az, zr, st);
+            int rc = launch_nn(DIM, src, w.tgtp, Tk, act, prev, dedup ? w.ulist : nullptr, w.ucnt, B, N, pl, keys, w.seed0, az, zr, w.tdec, st);
             if (rc != MMK_OK) return rc;
         }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
@@ -1788,7 +1797,7 @@ extern "C" int mmk_pack_target(const float *target, int32_t B, int32_t M, int32_
     MMK_REQUIRE((dim == 2 || dim == 3) && tgt_cols >= dim, "mmk_pack_target: dim must be 2|3 and <= tgt_cols");
     const int Mpad = mmk_nn_padded_m(M);
     hipLaunchKernelGGL(pack_target_kernel, dim3(Mpad / 256, B), dim3(256), 0, (hipStream_t)stream, target, M, tgt_cols,
-                       dim, Mpad, target_planar);
+                       dim, Mpad, target_planar, static_cast<float *>(nullptr), 1);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -1817,7 +1826,7 @@ extern "C" int mmk_nn_search(const float *source, const float *target_planar, co
     }
     hipStream_t st = (hipStream_t)stream;
     MMK_CHECK_HIP(hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * N, st));
-    int rc = launch_nn(dim, source, target_planar, T, nullptr, nullptr, nullptr, nullptr, B, N, pl, packed, seed0, nullptr, nullptr, st);
+    int rc = launch_nn(dim, source, target_planar, T, nullptr, nullptr, nullptr, nullptr, B, N, pl, packed, seed0, nullptr, nullptr, nullptr, st);
     if (rc != MMK_OK) return rc;
     hipLaunchKernelGGL(nn_unpack_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, packed, B * N, idx, d2);
     MMK_LAUNCH_CHECK();
@@ -1877,8 +1886,12 @@ extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, con
     }
     hipStream_t st = (hipStream_t)stream;
     const int B = p->B;
-    rc = mmk_pack_target(target, B, p->M, p->tgt_cols, p->dim, w.tgtp, stream);
-    if (rc != MMK_OK) return rc;
+    {
+        const int Mpad = mmk_nn_padded_m(p->M);
+        hipLaunchKernelGGL(pack_target_kernel, dim3(Mpad / 256, B), dim3(256), 0, st, target, p->M, p->tgt_cols, p->dim, Mpad, w.tgtp,
+                           w.tdec, NN_COARSE_STRIDE);
+        MMK_LAUNCH_CHECK();
+    }
     MMK_CHECK_HIP(hipMemcpyAsync(T_hist, T_init, sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, active_hist, B, 1);
     MMK_LAUNCH_CHECK();
