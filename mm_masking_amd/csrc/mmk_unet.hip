@@ -2218,8 +2218,18 @@ __global__ __launch_bounds__(320) void conv_first_wgrad_reduce_kernel(const floa
 {
     __shared__ float sh[4][80];
     const int c = blockIdx.x, i = threadIdx.x % 80, q = threadIdx.x / 80;
+    // (same order of additions as a plain loop; eight loads in flight instead of one dependent load per addition, which
+    // made this 160 KB reduction a 32 us kernel)
     float v = 0.f;
-    for (int b = q; b < nblk; b += 4) v += part[((size_t)b * CIN + c) * 80 + i];
+    int b = q;
+    for (; b + 28 < nblk; b += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[((size_t)(b + 4 * u) * CIN + c) * 80 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; b < nblk; b += 4) v += part[((size_t)b * CIN + c) * 80 + i];
     sh[q][i] = v;
     __syncthreads();
     if (q == 0) {
