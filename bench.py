@@ -4,7 +4,9 @@ sampling -> 10-iteration point-to-plane Huber dICP -> loss -> backward -> Adam) 
 synthetic 400x3360 radar scans against 20k-point lidar submaps.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is a rank; started
+   plainly with --gpus N > 1 it is the launcher: before any GPU call it spawns N fresh rank processes through
+   ``python -m torch.distributed.run``, relays rank 0's JSON line and exits non-zero if any rank failed.)
 
 Prints ONE JSON line on rank 0 (contract: task prompt / DESIGN.md §6):
   value      = whole-job scan-pairs/s, inputs resident in HBM before the timed region
@@ -58,6 +60,64 @@ def progress(msg):
     """Progress lines on stderr (the JSON result is the only thing on stdout)."""
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench %7.1fs] %s" % (time.time() - _T_START, msg), file=sys.stderr, flush=True)
+
+
+def launcher_command(argv, n, port, python=None):
+    """The command the launcher starts: torch.distributed.run with one rank per GPU on this node, rendezvous on
+    127.0.0.1 (the container's hostname may not resolve), followed by this script and its own arguments."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def pick_result_line(stdout_text):
+    """Rank 0's JSON line out of everything the ranks wrote to stdout (backends print banners there): the LAST line
+    that parses as a JSON object with a "metric" key; None when there is none."""
+    found = None
+    for line in stdout_text.splitlines():
+        line = line.strip()
+        if not (line.startswith("{") and line.endswith("}")):
+            continue
+        try:
+            obj = json.loads(line)
+        except ValueError:
+            continue
+        if isinstance(obj, dict) and "metric" in obj:
+            found = line
+    return found
+
+
+def launch_ranks(argv, n, runner=None):
+    """--gpus N > 1 without WORLD_SIZE: be the launcher.  Nothing in this process has touched the GPU (no torch.cuda
+    call, no HIP call): the ranks are fresh child processes, never an exec of a process that initialised the device.
+    Returns the exit code: the children's when non-zero, 3 when they succeeded without printing a result line."""
+    import socket
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0"))
+    if port == 0:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = launcher_command(argv, n, port)
+    progress("launcher: " + " ".join(cmd))
+    run = runner or (lambda c, e: subprocess.run(c, env=e, stdout=subprocess.PIPE, text=True))
+    proc = run(cmd, env)
+    line = pick_result_line(proc.stdout or "")
+    if proc.returncode != 0:
+        sys.stderr.write("[bench] a rank failed: torch.distributed.run exited with %d\n" % proc.returncode)
+        if proc.stdout:
+            sys.stderr.write(proc.stdout[-4000:])
+        return proc.returncode
+    if line is None:
+        sys.stderr.write("[bench] the ranks exited cleanly but rank 0 printed no result line\n")
+        return 3
+    print(line)
+    sys.stdout.flush()
+    return 0
 
 
 def nn_algorithmic_bytes(B):
@@ -307,6 +367,8 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (sparse scenes, dim 3, inference)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -397,6 +459,8 @@ def main():
     progress("timing %d steps" % args.steps)
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))
+    if sync is not None:
+        sync.timing, sync.calls = [], 0
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
@@ -420,10 +484,27 @@ def main():
     n_rec = ctypes.c_int32(0)
     _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
     nn_ms = np.array(ms[:min(n_rec.value, cap)], dtype=np.float64)
+    ddp_block = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        # what the process group saw, from the group itself: every rank contributes its own wall time and the mean
+        # duration of its gradient all-reduces (events on the stream the collective is ordered on)
+        ar_ms = [a.elapsed_time(b) for a, b in (sync.timing or [])]
+        sync.timing = None
+        mine = torch.tensor([dt, float(np.mean(ar_ms)) if ar_ms else float("nan"), float(np.max(ar_ms)) if ar_ms else float("nan")],
+                            dtype=torch.float64, device=device)
+        everyone = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(everyone, mine)
+        rows = torch.stack(everyone).cpu().numpy()
+        dt = float(rows[:, 0].max())                # MAX over ranks, as the contract says
+        ddp_block = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "rank_count_reporting": int(len(rows)),
+                     "allreduce_bytes": sync.allreduce_bytes(), "allreduce_calls_per_step": sync.calls / float(args.steps),
+                     "allreduce_ms": float(np.nanmean(rows[:, 1])), "allreduce_ms_max_over_ranks_and_steps": float(np.nanmax(rows[:, 2])),
+                     "ms_per_step_min_over_ranks": float(rows[:, 0].min()) / args.steps * 1e3,
+                     "ms_per_step_max_over_ranks": float(rows[:, 0].max()) / args.steps * 1e3,
+                     "devices_visible": torch.cuda.device_count(), "global_minmax": bool(getattr(model, "global_minmax", False)),
+                     "note": "one flat fp32 sum all-reduce of the U-Net backward's own gradient block per step (mm_masking_amd/ddp.py); "
+                             "allreduce_ms = mean over ranks of the mean event time around the collective, which includes waiting for "
+                             "the slowest rank to arrive"}
 
     # host cost of enqueueing one step, measured with an EMPTY launch queue (synchronise, time the Python call, synchronise):
     # inside the timed loop the host runs ahead until the queue is full and then waits for the GPU, so the loop's host
@@ -531,6 +612,8 @@ def main():
                                  "pairs, not HBM" % evals,
                          "binding": binding},
         }
+        if ddp_block is not None:
+            result["ddp"] = ddp_block
         if world == 1:
             result["conv_stack"] = conv_stack_rate(model, raws[0], params, device)
             if model.ICP_alg.nn_search == "brute" and not args.no_grid:

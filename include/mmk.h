@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 301 /* 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
+#define MMK_VERSION 400 /* 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -96,6 +96,32 @@ int mmk_icp_backward(const mmk_icp_params *p, const float *source, const float *
                      const int32_t *active_hist, const float *grad_T /*B,16*/,
                      float *grad_weight /*B,N*/, float *grad_T_init /*B,16 or NULL*/,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Status of the last mmk_icp_forward call that used `workspace`: the MMK_ICP_STATUS_* bits its kernels raised (0 = clean).
+ * Asynchronous like everything else: enqueues a 4-byte copy on `stream` into status_out (a device pointer or pinned host
+ * memory); the value is valid once the stream has passed it.  MMK_ICP_STATUS_UNARMED_KEY: a source row reached the
+ * accumulation stage with a nearest-neighbour key no search kernel wrote (or an index outside the target) -- an internal
+ * error, never the result of the caller's data; the row was clamped to stay in bounds and the poses of that call are
+ * not to be trusted.                                                                                                     */
+#define MMK_ICP_STATUS_UNARMED_KEY 1
+int mmk_icp_status(const mmk_icp_params *p, const void *workspace, size_t workspace_bytes,
+                   int32_t *status_out, void *stream);
+
+/* The stages of one iteration on their own (SURVEY.md 8b names them; mmk_icp_forward is these in a loop behind the NN search).
+ * mmk_icp_accumulate (stages I3 + I4): consumes nearest-neighbour keys ((bits of d2) << 32 | index, (B,N) uint64 -- the
+ * layout the search kernels produce), writes the correspondences idx_out (B,N) and per-workgroup partial sums of the normal
+ * equations, `partials` fp64 with mmk_icp_partials_count(p) elements ((B, ceil(N/256), 9 | 27): upper triangle of A row-major,
+ * then b); ORs MMK_ICP_STATUS_* bits into the device word *status (caller zeroes it).  T (B,16) = the pose the keys were
+ * found under.  mmk_icp_solve_update (stages I5 + I6): ordered sum of the partials, Cholesky solve, T_out = Exp(delta) T_in,
+ * delta_out (B,6), A_out (B,36), active_out[b] = 0 once ||delta|| < tolerance (active_in[b] = 0: pair frozen, pose copied). */
+size_t mmk_icp_partials_count(const mmk_icp_params *p);
+int mmk_icp_accumulate(const mmk_icp_params *p, const float *source, const float *target,
+                       const float *weight /*B,N or NULL*/, const float *T /*B,16*/,
+                       const uint64_t *nn_keys /*B,N*/, int32_t *idx_out /*B,N*/, double *partials,
+                       int32_t *status /*device, 1*/, void *stream);
+int mmk_icp_solve_update(const mmk_icp_params *p, const double *partials, const float *T_in /*B,16*/,
+                         float *T_out /*B,16*/, double *delta_out /*B,6*/, double *A_out /*B,36*/,
+                         const int32_t *active_in /*B*/, int32_t *active_out /*B*/, void *stream);
 
 /* Stand-alone brute-force nearest neighbour (stage I2), the roofline kernel.
  * target_planar: (B,dim,Mpad) produced by mmk_pack_target, Mpad = mmk_nn_padded_m(M).

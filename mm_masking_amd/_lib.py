@@ -115,6 +115,10 @@ def _declare(lib):
         "mmk_icp_workspace_bytes": (sz, [P]),
         "mmk_icp_forward": (ctypes.c_int, [P] + [c_vp] * 10 + [c_vp, sz, ctypes.POINTER(ctypes.c_int), c_vp]),
         "mmk_icp_backward": (ctypes.c_int, [P] + [c_vp] * 11 + [c_vp, sz, c_vp]),
+        "mmk_icp_status": (ctypes.c_int, [P, c_vp, sz, c_vp, c_vp]),
+        "mmk_icp_partials_count": (sz, [P]),
+        "mmk_icp_accumulate": (ctypes.c_int, [P] + [c_vp] * 8 + [c_vp]),
+        "mmk_icp_solve_update": (ctypes.c_int, [P] + [c_vp] * 7 + [c_vp]),
         "mmk_nn_padded_m": (i32, [i32]),
         "mmk_pack_target": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_nn_workspace_bytes": (sz, [i32, i32, i32, i32]),

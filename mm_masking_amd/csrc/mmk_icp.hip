@@ -998,13 +998,13 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
     const unsigned long long *__restrict__ packed, unsigned long long *__restrict__ packed_next,
     const int32_t *__restrict__ allzero, const int32_t *__restrict__ zrep, int nn_pts, int nn_nsb,
     int32_t *__restrict__ idx_out, int N, int M, int loss, float k,
-    float k2, float trim2, double *__restrict__ partials)
+    float k2, float trim2, double *__restrict__ partials, int32_t *__restrict__ status)
 {
     constexpr int P = PointTerms<DIM, TYPE>::P;
     constexpr int NR = PointTerms<DIM, TYPE>::NR;
     constexpr int NACC = nacc(DIM);
     const int b = blockIdx.y;
-    if (active[b] == 0) return;
+    if (active != nullptr && active[b] == 0) return;
     const int i = blockIdx.x * ACC_THREADS + threadIdx.x;
     double acc[NACC];
 #pragma unroll
@@ -1019,9 +1019,14 @@ __global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
         int isrc = i;
         if (allzero != nullptr && allzero[(size_t)b * nn_nsb + i / nn_pts] != 0 && zrep[b] < (i / nn_pts) * nn_pts) isrc = zrep[b];
         const unsigned long long key = packed[(size_t)b * N + isrc];
-        packed_next[(size_t)b * N + i] = NN_KEY_INIT;
-        // (an index outside the target can only come from a key nobody armed; it must not become an address)
-        const int j = min(max((int)(unsigned)(key & 0xffffffffull), 0), M - 1);
+        if (packed_next != nullptr) packed_next[(size_t)b * N + i] = NN_KEY_INIT;
+        // An index outside the target can only come from a key nobody armed (every NN engine writes each row's key: range 0
+        // of the scan always does, also for non-finite points).  It must not become an address -- and it must not pass
+        // silently as correspondence 0 either: the launch raises MMK_ICP_STATUS_UNARMED_KEY in the caller's status word
+        // (mmk_icp_status; dICP/ICP.py turns it into an MmkError), then clamps so that the rest of the launch stays in bounds.
+        const unsigned jraw = (unsigned)(key & 0xffffffffull);
+        if ((key == NN_KEY_INIT || jraw >= (unsigned)M) && status != nullptr) atomicOr(status, (int32_t)MMK_ICP_STATUS_UNARMED_KEY);
+        const int j = (int)min(jraw, (unsigned)(M - 1));
         idx_out[(size_t)b * N + i] = j;
         const float omega = weight ? weight[(size_t)b * N + i] : 1.f;
         PointTerms<DIM, TYPE> t;
@@ -1626,7 +1631,7 @@ struct IcpWs {
     double *partials;   // forward: (B,nblk,NACC); backward: pose parts (B,nblk,NP)
     double *G0, *G1;    // backward (B,16)
     double *lam;        // backward (B,6)
-    int32_t *host_flag_dev;
+    int32_t *status;             // (16): word 0 = MMK_ICP_STATUS_* bits raised by the kernels of the last forward call
     int32_t *g_counts, *g_cursor, *g_starts;  // grid NN: (B,NC), (B,NC), (B,NC+1)
     float4 *g_sorted;                          // grid NN: (B,M) x,y,z,index
     size_t bytes;
@@ -1650,7 +1655,7 @@ IcpWs carve(const mmk_icp_params *p, void *ws, size_t cap)
     w.G0 = ar.take<double>((size_t)p->B * 16);
     w.G1 = ar.take<double>((size_t)p->B * 16);
     w.lam = ar.take<double>((size_t)p->B * 6);
-    w.host_flag_dev = ar.take<int32_t>(16);
+    w.status = ar.take<int32_t>(16);
     w.g_counts = w.g_cursor = w.g_starts = nullptr;
     w.g_sorted = nullptr;
     if (p->nn_method == MMK_NN_GRID) {
@@ -1674,6 +1679,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
     MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)2 * B * N, st));
+    MMK_CHECK_HIP(hipMemsetAsync(w.status, 0, sizeof(int32_t) * 16, st));
     const bool use_grid = p->nn_method == MMK_NN_GRID;
     const int nn_pts = NN_THREADS * pl.P;
     const bool dedup = !use_grid && pl.nsb <= 0xfff && B < (1 << 19);
@@ -1721,7 +1727,7 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
         }
         hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, B), dim3(ACC_THREADS), 0, st, src, tgt,
                            p->tgt_cols, weight, Tk, act, keys, keys_next, az, zr, nn_pts, pl.nsb, idx, N, M, p->loss, k, k2, trim2,
-                           w.partials);
+                           w.partials, w.status);
         MMK_LAUNCH_CHECK();
         hipLaunchKernelGGL(icp_solve_kernel<DIM>, dim3(B), dim3(64), 0, st, w.partials, nblk, Tk,
                            T_hist + (size_t)(it + 1) * B * 16, delta_hist + (size_t)it * B * 6,
@@ -1907,6 +1913,78 @@ extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, con
     MMK_CHECK_HIP(hipMemcpyAsync(T_out, T_hist + (size_t)p->max_iter * B * 16, sizeof(float) * B * 16,
                                  hipMemcpyDeviceToDevice, st));
     return MMK_OK;
+}
+
+extern "C" int mmk_icp_status(const mmk_icp_params *p, const void *workspace, size_t workspace_bytes, int32_t *status_out,
+                              void *stream)
+{
+    int rc = check_params(p);
+    if (rc != MMK_OK) return rc;
+    MMK_REQUIRE(status_out != nullptr, "mmk_icp_status: NULL status_out");
+    const IcpWs w = carve(p, const_cast<void *>(workspace), workspace_bytes);
+    if (workspace == nullptr || w.bytes > workspace_bytes) {
+        mmk::set_error("mmk_icp_status: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+        return MMK_ERR_WORKSPACE;
+    }
+    MMK_CHECK_HIP(hipMemcpyAsync(status_out, w.status, sizeof(int32_t), hipMemcpyDefault, (hipStream_t)stream));
+    return MMK_OK;
+}
+
+extern "C" size_t mmk_icp_partials_count(const mmk_icp_params *p)
+{
+    if (check_params(p) != MMK_OK) return 0;
+    return (size_t)p->B * ((p->N + ACC_THREADS - 1) / ACC_THREADS) * nacc(p->dim);
+}
+
+namespace {
+template <int DIM, int TYPE>
+int run_accumulate(const mmk_icp_params *p, const float *src, const float *tgt, const float *weight, const float *T,
+                   const unsigned long long *keys, int32_t *idx, double *partials, int32_t *status, hipStream_t st)
+{
+    const int nblk = (p->N + ACC_THREADS - 1) / ACC_THREADS;
+    hipLaunchKernelGGL((icp_accumulate_kernel<DIM, TYPE>), dim3(nblk, p->B), dim3(ACC_THREADS), 0, st, src, tgt, p->tgt_cols, weight,
+                       T, static_cast<const int32_t *>(nullptr), keys, static_cast<unsigned long long *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), static_cast<const int32_t *>(nullptr), 1, 1, idx, p->N, p->M, p->loss,
+                       p->loss_k, p->loss_k * p->loss_k, p->trim_dist * p->trim_dist, partials, status);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+template <int DIM>
+int run_solve_update(const mmk_icp_params *p, const double *partials, const float *T_in, float *T_out, double *delta, double *A,
+                     const int32_t *active_in, int32_t *active_out, hipStream_t st)
+{
+    const int nblk = (p->N + ACC_THREADS - 1) / ACC_THREADS;
+    hipLaunchKernelGGL(icp_solve_kernel<DIM>, dim3(p->B), dim3(64), 0, st, partials, nblk, T_in, T_out, delta, A, active_in, active_out,
+                       p->tolerance);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+}  // namespace
+
+extern "C" int mmk_icp_accumulate(const mmk_icp_params *p, const float *source, const float *target, const float *weight,
+                                  const float *T, const uint64_t *nn_keys, int32_t *idx_out, double *partials, int32_t *status,
+                                  void *stream)
+{
+    int rc = check_params(p);
+    if (rc != MMK_OK) return rc;
+    MMK_REQUIRE(source && target && T && nn_keys && idx_out && partials && status, "mmk_icp_accumulate: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned long long *keys = reinterpret_cast<const unsigned long long *>(nn_keys);
+    if (p->dim == 2 && p->icp_type == MMK_ICP_PT2PT) return run_accumulate<2, MMK_ICP_PT2PT>(p, source, target, weight, T, keys, idx_out, partials, status, st);
+    if (p->dim == 2) return run_accumulate<2, MMK_ICP_PT2PL>(p, source, target, weight, T, keys, idx_out, partials, status, st);
+    if (p->icp_type == MMK_ICP_PT2PT) return run_accumulate<3, MMK_ICP_PT2PT>(p, source, target, weight, T, keys, idx_out, partials, status, st);
+    return run_accumulate<3, MMK_ICP_PT2PL>(p, source, target, weight, T, keys, idx_out, partials, status, st);
+}
+
+extern "C" int mmk_icp_solve_update(const mmk_icp_params *p, const double *partials, const float *T_in, float *T_out,
+                                    double *delta_out, double *A_out, const int32_t *active_in, int32_t *active_out, void *stream)
+{
+    int rc = check_params(p);
+    if (rc != MMK_OK) return rc;
+    MMK_REQUIRE(partials && T_in && T_out && delta_out && A_out && active_in && active_out, "mmk_icp_solve_update: NULL pointer");
+    if (p->dim == 2) return run_solve_update<2>(p, partials, T_in, T_out, delta_out, A_out, active_in, active_out, (hipStream_t)stream);
+    return run_solve_update<3>(p, partials, T_in, T_out, delta_out, A_out, active_in, active_out, (hipStream_t)stream);
 }
 
 extern "C" int mmk_icp_backward(const mmk_icp_params *p, const float *source, const float *target,

@@ -53,9 +53,60 @@ def _state_buffers(p, device):
     }
 
 
+ICP_STATUS_UNARMED_KEY = 1          # include/mmk.h: MMK_ICP_STATUS_UNARMED_KEY
+
+
+class _StatusWatch:
+    """Device-side error flags of the ICP kernels, checked WITHOUT synchronising the step: every forward call enqueues a
+    4-byte copy of its status word into a pinned host slot behind its kernels (mmk_icp_status) plus an event; the slots
+    whose event has completed are examined at the next ICP call (and by ``check(wait=True)``).  A raised flag is an
+    internal error of the library (a nearest-neighbour key that no search kernel wrote) and becomes an MmkError instead
+    of a silently clamped correspondence."""
+
+    def __init__(self):
+        self.pending = []           # (event, pinned int32 tensor)
+        self.free = []
+
+    def watch(self, p, ws, dev):
+        L = _lib.lib()
+        slot = self.free.pop() if self.free else torch.zeros(1, dtype=torch.int32).pin_memory()
+        _lib.check(L.mmk_icp_status(ctypes.byref(p), _lib.ptr(ws), ws.numel(), ctypes.c_void_p(slot.data_ptr()),
+                                    _lib.stream_ptr(dev)))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.pending.append((ev, slot))
+
+    def check(self, wait=False):
+        keep = []
+        bad = 0
+        for ev, slot in self.pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                bad |= int(slot[0])
+                self.free.append(slot)
+            else:
+                keep.append((ev, slot))
+        self.pending = keep
+        if bad & ICP_STATUS_UNARMED_KEY:
+            raise _lib.MmkError("dICP: a source row reached the accumulation stage with a nearest-neighbour key that no search "
+                                "kernel wrote (MMK_ICP_STATUS_UNARMED_KEY) -- internal error, the poses of that call are invalid")
+        if bad:
+            raise _lib.MmkError("dICP: the ICP kernels raised status bits 0x%x" % bad)
+
+
+_status = _StatusWatch()
+
+
+def check_errors(wait=True):
+    """Raise if any ICP call so far raised a device-side error flag (``wait``: first wait for the calls in flight)."""
+    _status.check(wait=wait)
+
+
 def _forward(p, src, tgt, weight, T_init):
     L = _lib.lib()
     dev = src.device
+    _status.check()
     ws = _workspace(L.mmk_icp_workspace_bytes(ctypes.byref(p)), dev)
     st = _state_buffers(p, dev)
     T_out = torch.empty(p.B, 4, 4, dtype=torch.float32, device=dev)
@@ -65,6 +116,7 @@ def _forward(p, src, tgt, weight, T_init):
                                  _lib.ptr(T_init, torch.float32, "T_init"), _lib.ptr(T_out), _lib.ptr(st["idx"]),
                                  _lib.ptr(st["T"]), _lib.ptr(st["delta"]), _lib.ptr(st["A"]), _lib.ptr(st["active"]),
                                  _lib.ptr(ws), ws.numel(), ctypes.byref(iters), _lib.stream_ptr(dev)))
+    _status.watch(p, ws, dev)
     return T_out, st, iters.value
 
 

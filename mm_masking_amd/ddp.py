@@ -28,6 +28,10 @@ class FlatGradSync:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self._attach()
+        # measurement hook (bench.py's ``ddp`` block): when a list, every collective appends a (start, end) pair of
+        # events recorded on the current stream around it
+        self.timing = None
+        self.calls = 0
 
     def _attach(self):
         for p, v in zip(self.params, self.views):
@@ -81,8 +85,20 @@ class FlatGradSync:
                     v.copy_(p.grad)
                 p.grad = v
         if ws > 1:
+            ev = None
+            if self.timing is not None and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            if ev is not None:
+                ev[1].record()
+                self.timing.append(ev)
+            self.calls += 1
             self.flat.div_(ws)
+
+    def allreduce_bytes(self):
+        """Bytes one gradient all-reduce moves per rank (the flat fp32 buffer)."""
+        return int(self.flat.numel()) * 4
 
 
 def shard_indices(global_batch, rank, world_size, start=0):

@@ -99,10 +99,12 @@ class LearnICPWeightPolicy(nn.Module):
         # data-parallel jobs: reduce the min-max normalisation's extrema over the ranks (one MAX all-reduce of 2C floats), so
         # that it stays global over the whole batch as in the single-process reference (icp_weight_policy.py:151-155).
         # Default: ON whenever the process is a rank of a multi-rank job, so that N ranks x B pairs normalise like one
-        # process over N*B pairs; params["global_minmax"] = False keeps it per rank.
-        import torch.distributed as dist
-        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.global_minmax = bool(params.get("global_minmax", multi_rank))
+        # process over N*B pairs; params["global_minmax"] = False keeps it per rank.  The default is resolved at forward
+        # time (the ``global_minmax`` property), so a model built before init_process_group normalises globally too.
+        # The reduction is a COLLECTIVE: every rank must run the same number of forwards (training and validation
+        # alike) -- train_icp_weights.fit() validates on all ranks for this reason.
+        gm = params.get("global_minmax", None)
+        self._global_minmax = None if gm is None else bool(gm)
         self._step = 0
 
         self.mean_num_pts = 0.0
@@ -121,6 +123,19 @@ class LearnICPWeightPolicy(nn.Module):
         self.final_layer = nn.Sequential(nn.Conv2d(dec_channels[-1], 1, kernel_size=1), nn.Sigmoid())
         if params["init_weights"]:
             self.apply(weights_init)
+
+    @property
+    def global_minmax(self):
+        """Whether the min-max extrema are reduced over the ranks: the explicit params["global_minmax"] / assigned value,
+        else "this process is a rank of a multi-rank job" -- asked when used, not when the model was built."""
+        if self._global_minmax is not None:
+            return self._global_minmax
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    @global_minmax.setter
+    def global_minmax(self, value):
+        self._global_minmax = None if value is None else bool(value)
 
     def conv_block(self, in_channels, out_channels, i=0):
         """icp_weight_policy.py:104-125 (module order fixes the state_dict keys)."""

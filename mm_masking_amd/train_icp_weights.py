@@ -289,7 +289,10 @@ def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_
     the total validation norm improves (or at epoch 0), ``epoch_N.pt`` every epoch (both bare
     state_dicts, as upstream), and finally a validation of the best policy.  Additionally writes
     ``resume.pt`` (save_checkpoint) every epoch; pass ``start_epoch`` / ``best_norm`` from
-    ``load_checkpoint`` to continue a run.  Returns a history dict."""
+    ``load_checkpoint`` to continue a run.  Returns a history dict.
+
+    Multi-rank jobs: every rank calls fit() with iterators of the SAME length (baselines, validation and training
+    forwards may each hold the global min-max collective); ``is_main`` only gates the files that are written."""
     import os
     dev = params["device"]
     lw = loss_weights if loss_weights is not None else loss_weights_from(params)
@@ -333,11 +336,35 @@ def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_
         log("EPOCH %d  loss %.5f  norm %.5f  best %.5f  (train %.1f s, val %.1f s)" % (epoch, mean_loss, total, best_norm,
                                                                                       t_train, t_val))
     hist["best_norm"] = best_norm
-    if is_main and os.path.exists(best_path):
-        policy.load_state_dict(torch.load(best_path, map_location=dev, weights_only=True))
+    # Final validation of the best policy (train_icp_weights.py:577-596), on EVERY rank of a multi-rank job: a forward
+    # may hold a collective (the global min-max normalisation), so a validation that only the main rank entered would
+    # hang or pair with another rank's next collective.  The main rank reads best_policy.pt and its weights are
+    # broadcast, so the ranks end the run with identical (best) parameters.
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    have_best = is_main and os.path.exists(best_path)
+    if multi:
+        flag = torch.tensor([1.0 if have_best else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        have_best = bool(flag.item() > 0)
+    if have_best:
+        if is_main and os.path.exists(best_path):
+            policy.load_state_dict(torch.load(best_path, map_location=dev, weights_only=True))
+        if multi:
+            src = _main_rank(is_main, dev)
+            for t in policy.state_dict().values():
+                dist.broadcast(t, src=src)
         hist["final_acc"] = [float(v) for v in validate_policy(policy, validation_iterator, device=dev,
                                                               binary=params["binary_inference"], gt_eye=params["gt_eye"])[0][0]]
     return hist
+
+
+def _main_rank(is_main, dev):
+    """The rank that passed is_main=True (the lowest one, should several have): found with one MIN all-reduce."""
+    import torch.distributed as dist
+    t = torch.tensor([float(dist.get_rank()) if is_main else float(dist.get_world_size())], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
 
 
 class SyntheticIterator:

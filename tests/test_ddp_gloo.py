@@ -163,3 +163,130 @@ def test_policy_host_logic_two_ranks_equal_one_process():
     # so compare the parameter UPDATE (lr 1e-4, two steps) rather than bits
     assert torch.allclose(out[0][0], ref, atol=2e-5), float((out[0][0] - ref).abs().max())
     assert abs(out[0][1][0] - losses[0]) < 1e-6 and abs(out[0][1][1] - losses[1]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fit(): every collective of the epoch loop pairs up across the ranks (the final validation used to run on
+# the main rank alone while a forward holds the global min-max all-reduce)
+class _Batches:
+    """A fixed list of (scan, map, T) batches of `hw` x `hw` images, different per rank."""
+
+    def __init__(self, rank, n_batches, first, hw=32, b=2):
+        self.items = []
+        for k in range(n_batches):
+            idx = [first + 2 * (k * b + j) + rank for j in range(b)]
+            img = torch.cat([_scan(i, hw)[0] for i in idx])
+            T = torch.eye(4).repeat(b, 1, 1)
+            T[:, 0, 3] = torch.tensor([0.1 * (i % 5) for i in idx])
+            self.items.append({"loc_data": {"fft_data": img, "fft_cfar": (img > img.mean(dim=(1, 2), keepdim=True)).float(), "raw_pc": torch.rand(b, 4, 3),
+                                            "filtered_pc": torch.rand(b, 4, 3)},
+                               "map_data": {"pc": torch.rand(b, 4, 6)},
+                               "transforms": {"T_ml_init": T, "T_ml_gt": torch.eye(4).repeat(b, 1, 1)}})
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+
+def _fit_worker(rank, world, port, out, ckpt_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    torch.set_num_threads(2)
+    from mm_masking_amd import icp_weight_policy as pol
+    from mm_masking_amd import train_icp_weights as trn
+    # the model exists BEFORE the process group does: the global min-max default must still resolve to "on"
+    model, p = _policy(seed=20 + rank)
+    p.update({"num_epochs": 2, "loss_cfar_mask_weight": 1.0, "loss_map_pts_mask_weight": 0.0})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert model.global_minmax
+        n_forward = [0]
+
+        # the dICP / extract_weights kernels have no CPU path: host-logic stand-ins with the same shapes (the test is
+        # about which rank enters which collective, not about their arithmetic)
+        def stats_stub(mask, pts):
+            w = mask.mean(dim=(1, 2)).unsqueeze(1).expand(-1, pts.shape[1])
+            z = torch.zeros(())
+            return (w, z, 0.0, 0.0, 0.0, 0.0), [z] * 6
+
+        def icp_stub(scan_pc, map_pc, T_init, weights):
+            n_forward[0] += 1
+            return T_init * (1.0 + 0.01 * weights.mean())
+        pol._extract_weights_stats = stats_stub
+        model.icp = icp_stub
+        sync = ddp.FlatGradSync(model)
+        sync.sync_params(0)
+        opt = trn.make_optimizer(model, p)
+        hist = trn.fit(model, _Batches(rank, 2, 0), _Batches(rank, 1, 100), opt, p, ckpt_dir, grad_sync=sync,
+                       is_main=(rank == 0), log=lambda *_: None)
+        flat = torch.cat([q.detach().flatten() for q in model.parameters()])
+        out[rank] = (flat, hist.get("final_acc"), n_forward[0], sorted(os.listdir(ckpt_dir)) if rank == 0 else None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_two_ranks_final_validation_on_all_ranks(tmp_path):
+    """fit() on 2 gloo ranks with is_main = (rank == 0): returns on both ranks (no rank is left alone in a collective),
+    both run the same number of forwards incl. the final validation, both end with the best policy's parameters, and
+    only the main rank wrote files."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fit_worker, args=(world, port, out, str(tmp_path)), nprocs=world, join=True)
+    assert out[0][2] == out[1][2] > 0
+    assert out[0][1] is not None and out[1][1] is not None          # final validation ran on both
+    assert torch.equal(out[0][0], out[1][0])                        # identical (best) weights everywhere
+    best = torch.load(os.path.join(str(tmp_path), "best_policy.pt"), weights_only=True)
+    # best_policy.pt holds the state_dict in module order: same order as parameters()
+    ref = torch.cat([v.flatten() for k, v in best.items()])
+    assert torch.equal(out[0][0], ref)
+    assert {"best_policy.pt", "epoch_0.pt", "epoch_1.pt", "resume.pt"} <= set(out[0][3])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bench.py's launcher (python bench.py --gpus N without WORLD_SIZE): argument / exit-code logic, no GPU, no children
+def _bench():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["bench_under_test"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Proc:
+    def __init__(self, rc, out):
+        self.returncode, self.stdout = rc, out
+
+
+def test_bench_launcher_command_and_exit_codes(capsys, monkeypatch):
+    bench = _bench()
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "7"], 4, 29517, python="py")
+    assert cmd[:4] == ["py", "-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    # rank 0's line is found behind backend banners; other JSON-looking lines without "metric" are not it
+    good = '{"metric": "scan-pairs/s", "value": 1.0, "n_gpus": 2}'
+    text = "Gloo banner: connected\n{\"not\": \"it\"}\n" + good + "\ntrailing noise\n"
+    assert bench.pick_result_line(text) == good
+    assert bench.pick_result_line("nothing here\n") is None
+    monkeypatch.setenv("WORLD_SIZE", "7")       # must not leak into the children
+    seen = {}
+
+    def runner_ok(c, e):
+        seen["cmd"], seen["env"] = c, e
+        return _Proc(0, text)
+    assert bench.launch_ranks(["--gpus", "2"], 2, runner=runner_ok) == 0
+    assert capsys.readouterr().out.strip() == good                  # exactly one line on stdout
+    assert "WORLD_SIZE" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "2"
+    # a failing rank: its exit code is relayed and nothing goes to stdout
+    assert bench.launch_ranks(["--gpus", "2"], 2, runner=lambda c, e: _Proc(17, "partial\n")) == 17
+    assert capsys.readouterr().out == ""
+    # clean exit without a result line is an error too
+    assert bench.launch_ranks(["--gpus", "2"], 2, runner=lambda c, e: _Proc(0, "no json\n")) == 3
