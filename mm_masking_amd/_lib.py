@@ -79,7 +79,7 @@ def build(verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SOURCES]
-    common = [os.path.join(csrc, "mmk_common.h"), os.path.join(_ROOT, "include", "mmk.h")]
+    common = [os.path.join(csrc, "mmk_common.h"), os.path.join(csrc, "mmk_unet_shared.h"), os.path.join(_ROOT, "include", "mmk.h")]
     extra = {"mmk_unet.hip": [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".inc")]}
     objdir = os.path.join(csrc, "_obj")
     os.makedirs(objdir, exist_ok=True)

@@ -18,13 +18,11 @@
 #include <algorithm>
 
 #include "mmk_common.h"
+#include "mmk_unet_shared.h"
 
 namespace {
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+using namespace mmku;       // shared with mmk_conv_dx.hip: element types, ConvArgs, the dropout hash (mmk_unet_shared.h)
 
 constexpr int TH = 8, TW = 32;            // output pixels per block tile
 constexpr int HT = TH + 2, WT = TW + 2;   // halo tile
@@ -143,63 +141,6 @@ __global__ void pack_conv_weights_batch_kernel(const PackBatch pb)
     const int total = pb.total[l];
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
         pack_conv_weight_elem(pb.W[l], pb.cout[l], pb.cin[l], pb.transposed, pb.out[l], e);
-}
-
-struct ConvOutPart {
-    bf16 *y;               // (B,H,W,C)
-    const bf16 *relu_src;  // optional (B,H,W,C): y = acc * (relu_src > 0 ? scale : 0)
-    int C;
-    int accumulate;        // y += result
-    float scale;
-};
-
-struct ConvArgs {
-    const bf16 *x1, *x2;   // input = concat(x1 (C1 channels), x2 (C2 channels)); x2 may be null
-    int C1, C2;
-    const bf16 *wpack;
-    const float *bias;     // [COUT] or null
-    ConvOutPart o1, o2;    // output channels [0,o1.C) -> o1, [o1.C, o1.C+o2.C) -> o2
-    int B, H, W, CIN, COUT;
-    int relu;
-    float slope;           // > 0: nn.LeakyReLU(slope) instead of ReLU (forward), and the negative-side factor
-                           // slope * scale of the relu_src epilogues (backward); 0 = plain ReLU
-    float drop_p;          // forward dropout on the output (0 = none)
-    unsigned seed;
-    bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
-};
-
-__device__ __forceinline__ unsigned hash_u32(unsigned x)
-{
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-
-// Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index
-// e4 (a multiple of 4): one full avalanche hash per group of 4 + one cheap re-mix, 16 random bits
-// per element compared against thr = round(p * 65536).  (32-bit integer multiplies are quarter
-// rate on the VALU; a hash per element costs more than the convolution of an 8-channel layer.)
-struct DropoutParams {
-    unsigned thr;      // drop when the 16-bit draw is below thr
-    float inv_keep;    // 1 / (1 - thr / 65536): exactly unbiased for the quantised probability
-};
-
-__host__ __device__ inline DropoutParams dropout_params(float p)
-{
-    DropoutParams d;
-    d.thr = (unsigned)(p * 65536.0f + 0.5f);
-    d.inv_keep = d.thr ? 65536.0f / (float)(65536u - d.thr) : 1.0f;
-    return d;
-}
-
-__device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const DropoutParams &d, float (&sc)[4])
-{
-    const unsigned h1 = hash_u32(e4 * 0x9E3779B9U + seed);
-    unsigned h2 = h1 ^ 0x85ebca6bU;
-    h2 ^= h2 >> 16; h2 *= 0x7feb352dU; h2 ^= h2 >> 15;
-    sc[0] = ((h1 & 0xffffu) >= d.thr) ? d.inv_keep : 0.f;
-    sc[1] = ((h1 >> 16) >= d.thr) ? d.inv_keep : 0.f;
-    sc[2] = ((h2 & 0xffffu) >= d.thr) ? d.inv_keep : 0.f;
-    sc[3] = ((h2 >> 16) >= d.thr) ? d.inv_keep : 0.f;
 }
 
 // LeakyReLU variant of the network (params["leaky"], icp_weight_policy.py:106: nn.LeakyReLU(0.1)).
@@ -447,7 +388,6 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
 //   * each XCD walks its own contiguous range of tiles, so halo rows shared by neighbouring
 //     tiles hit that XCD's L2.
 // native vector type: the HIP uint4 struct is copied by memcpy, which keeps a register ring in scratch
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ u32x4 g_zero16;   // zero-initialised, never written
 __device__ u32x4 g_sink16[8]; // write-only: where lanes without an output element store
 

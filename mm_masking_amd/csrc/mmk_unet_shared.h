@@ -1,0 +1,82 @@
+// Types and helpers of the mask U-Net kernels (mmk_unet.hip and the experiment kept as scripts/experiments/r04_conv_dx_kernel.hip).
+#pragma once
+#include "mmk_common.h"
+
+namespace mmku {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// native vector type: the HIP uint4 struct is copied by memcpy, which keeps a register ring in scratch
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvOutPart {
+    bf16 *y;               // (B,H,W,C)
+    const bf16 *relu_src;  // optional (B,H,W,C): y = acc * (relu_src > 0 ? scale : 0)
+    int C;
+    int accumulate;        // y += result
+    float scale;
+};
+
+struct ConvArgs {
+    const bf16 *x1, *x2;   // input = concat(x1 (C1 channels), x2 (C2 channels)); x2 may be null
+    int C1, C2;
+    const bf16 *wpack;
+    const float *bias;     // [COUT] or null
+    ConvOutPart o1, o2;    // output channels [0,o1.C) -> o1, [o1.C, o1.C+o2.C) -> o2
+    int B, H, W, CIN, COUT;
+    int relu;
+    float slope;           // > 0: nn.LeakyReLU(slope) instead of ReLU (forward), and the negative-side factor
+                           // slope * scale of the relu_src epilogues (backward); 0 = plain ReLU
+    float drop_p;          // forward dropout on the output (0 = none)
+    unsigned seed;
+    bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
+};
+
+// Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index e4 (a multiple of 4): four
+// 16-bit draws compared against thr = round(p * 65536).  Round 4: the draws come from a hash built on FULL-RATE 24-bit
+// multiplies (v_mad_u32_u24 / v_mul_u32_u24).  The avalanche hash of rounds 1-3 used 32-bit multiplies, which are quarter
+// rate on the VALU: three of them per four values were half of the forward epilogues of the issue-bound kernels (switching
+// dropout off moved the thin 640 x 640 forward launches by 13-30 us each).  Nothing downstream depends on
+// WHICH elements are dropped -- the backward kernels read the mask back from the stored activation -- only on the rate and
+// on independence: checked offline on 4M indices and three seeds (drop rates within 0.5 % of thr / 65536; correlation between
+// the four draws, between neighbouring groups, pixels and image rows all <= 1e-3; scripts/dropout_hash_check.py).
+struct DropoutParams {
+    unsigned thr;      // drop when the 16-bit draw is below thr
+    float inv_keep;    // 1 / (1 - thr / 65536): exactly unbiased for the quantised probability
+};
+
+__host__ __device__ inline DropoutParams dropout_params(float p)
+{
+    DropoutParams d;
+    d.thr = (unsigned)(p * 65536.0f + 0.5f);
+    d.inv_keep = d.thr ? 65536.0f / (float)(65536u - d.thr) : 1.0f;
+    return d;
+}
+
+__device__ __forceinline__ void dropout_draws4(unsigned seed, unsigned e4, unsigned (&d)[4])
+{
+    const unsigned i = e4 >> 2;                       // group number; bits above 2^24 go into the seed
+    unsigned h = __umul24(i, 0x9E3779u) + (seed + __umul24(i >> 24, 0x9E3779u));
+    h ^= h >> 13;
+    h = __umul24(h, 0x85EBCBu);
+    h ^= h >> 11;
+    h = __umul24(h, 0xC2B2AFu);
+    h ^= h >> 15;
+    unsigned g = h ^ 0x85ebca6bU;
+    g ^= g >> 12;
+    g = __umul24(g, 0x7FEB35u);
+    g ^= g >> 14;
+    d[0] = h & 0xffffu; d[1] = h >> 16; d[2] = g & 0xffffu; d[3] = g >> 16;
+}
+
+__device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const DropoutParams &d, float (&sc)[4])
+{
+    unsigned dr[4];
+    dropout_draws4(seed, e4, dr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = (dr[r] >= d.thr) ? d.inv_keep : 0.f;
+}
+
+}  // namespace mmku

@@ -206,8 +206,9 @@ def test_icp_stage_entries_equal_one_forward_iteration_and_flag_unarmed_keys(dim
     correspondence."""
     import ctypes
     from mm_masking_amd import _lib
-    from mm_masking_amd.dICP import ICP as icp_mod
-    from mm_masking_amd.dICP.ICP import ICP
+    import importlib
+    icp_mod = importlib.import_module("mm_masking_amd.dICP.ICP")       # the module (the package re-exports the class under the same name)
+    ICP = icp_mod.ICP
     L = _lib.lib()
     rng = np.random.default_rng(40 + dim)
     B, N, M = 3, 700, 2100

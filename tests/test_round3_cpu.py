@@ -196,4 +196,9 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
         kernels += len(sizes)
         bad = [(n, s) for n, s in zip(kernel_names, sizes) if int(s) != 0]
         assert not bad, "kernels with scratch memory: %r" % bad
+        # no kernel may ask for a run-time sized stack either (round 4: the failing round-3 code object had a fixed 48-byte
+        # segment and .uses_dynamic_stack false -- the descriptor was not the cause -- but a dynamic stack would defeat the
+        # size check above, so it is asserted too)
+        dyn = re.findall(r"\.uses_dynamic_stack:\s+(\S+)", notes)
+        assert len(dyn) == len(kernel_names) and all(d == "false" for d in dyn), dyn
     assert kernels >= 60
