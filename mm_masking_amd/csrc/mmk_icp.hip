@@ -416,17 +416,34 @@ __device__ __forceinline__ void split3(float x, __bf16 &x1, __bf16 &x2, __bf16 &
     x3 = (__bf16)(r - (float)x2);
 }
 
+// dim 3 (round 4): 21 k-slots -- 6 products per coordinate and the three pieces of |t|^2 -- fill two k-slices, i.e. two chained
+// MFMAs per (32 targets x 32 points); the target tile is staged 512 targets at a time so that the fragments still take 32 KB
+// (four blocks per CU by LDS; three by registers).  Error bound, same derivation with three coordinates: n = fl(|t|^2) carries
+// three roundings (3u |t|^2), the nine dropped products u/2 |t||p| (Cauchy-Schwarz over the coordinates), the 21 addends and the
+// chaining addition are charged 2u S each, S <= 1.02 (|t|^2 + 2 |t||p|): |E_j - e_j| <= 48u |t|^2 + 90.5u |t||p| <= G3(D) =
+// u (231.8 |p|^2 + 141.3 D).  The normative distance has one more fma: |d - D| <= 6u D, D_j* <= X (1 + 13u).  Hence
+// E_j* <= b + u (463.5 |p|^2 + 296 X), X <= (b + |p|^2)(1 + 145u) + 232u |p|^2, and thr(b) = b (1 + kappa) + 2 kappa |p|^2 with
+// kappa = 496u covers it with 15u |p|^2 to spare for its own evaluation (launch_nn passes 496u for dim 3, 360u for dim 2).
 template <int DIM>
-__global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
+__global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
     const float *__restrict__ src, const float *__restrict__ tgtp,
     const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx,
     const int32_t *__restrict__ ulist, const int32_t *__restrict__ ucnt, int ucap, int B,
     int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
     unsigned long long *__restrict__ packed)
 {
-    static_assert(DIM == 2 && NNM_GROUPS == 4, "the matrix-core filter is laid out for dim 2 (16 k-slots), 4 point groups per wave");
-    __shared__ __attribute__((aligned(16))) uint4 frag[NN_TILE / 32][64];        // 32 KB: A fragments of the tile
-    __shared__ __attribute__((aligned(16))) float lt[DIM][NN_TILE];               // 8 KB: the fp32 planes (exact re-scan)
+    static_assert((DIM == 2 || DIM == 3) && NNM_GROUPS == 4, "the matrix-core filter: 16 (dim 2) or 2 x 16 (dim 3) k-slots, 4 point groups per wave");
+    constexpr int KS = DIM == 2 ? 1 : 2;             // k-slices = chained MFMAs per chunk
+    constexpr int TT = NN_TILE / KS;                 // targets staged per sub-tile
+    constexpr int NCH = TT / 32;                     // chunks per sub-tile (one flag bit each)
+    constexpr int TPT = TT / NN_THREADS;             // targets a thread stages: 4 (dim 2) or 2 (dim 3)
+    __shared__ __attribute__((aligned(16))) uint4 frag[KS][NCH][64];             // 32 KB: A fragments of the sub-tile
+    // the fp32 planes (exact re-scan), 8 / 6 KB.  In the re-scan every lane reads the eight float4s of ITS OWN flagged chunk; laid
+    // out plainly, all chunks of one parity share eight 16-byte bank slots (up to 8-way conflicts among the 16 lanes the LDS
+    // serves together: 45 % of the kernel's LDS cycles were conflict cycles, profiles/r03_nn_pmc_counters.json).  So float4 h
+    // of chunk c sits at position h ^ ((c >> 1) & 7) of the chunk: 16 consecutive chunks then cover all sixteen slots at every
+    // h (no padding: the block's 40 KB are what lets four blocks share a CU).
+    __shared__ __attribute__((aligned(16))) float lt[DIM][TT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int ntiles = Mpad / NN_TILE;
@@ -464,11 +481,12 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
         // read as `half ? p[2 + q] : p[q]` they became a 48-byte scratch-memory array read back at a run-time offset; with that
         // build 16-lane groups of a wave now and then worked on wrong coordinates (correspondences that changed from run to
         // run; a NaN coordinate finds nothing, so keys that nobody armed).  The round trip is sound in isolation
-        // (scripts/ubench/scratch_roundtrip.hip); what failed in the full process is not established.  The
-        // library uses no scratch memory anywhere: tests/test_round3_cpu.py::test_no_kernel_uses_scratch_memory.
-        float px[NNM_GROUPS], py[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
+        // (scripts/ubench/scratch_roundtrip.hip) and so is the code object; what failed in the full
+        // process is not established.  The library uses no scratch memory anywhere:
+        // tests/test_round3_cpu.py::test_no_kernel_uses_scratch_memory.
+        float px[NNM_GROUPS], py[NNM_GROUPS], pz[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
         int jseed[NNM_GROUPS];
-        nn_bf16x8 bfr[NNM_GROUPS];
+        nn_bf16x8 bfr[KS][NNM_GROUPS];
         unsigned w[NNM_GROUPS];
 #pragma unroll
         for (int g = 0; g < NNM_GROUPS; ++g) {
@@ -485,16 +503,28 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             transform_point<DIM>(T, s, tp);
             px[g] = tp[0];
             py[g] = tp[1];
-            const float pn = tp[0] * tp[0] + tp[1] * tp[1];
+            pz[g] = DIM == 3 ? tp[DIM - 1] : 0.f;
+            float pn = tp[0] * tp[0] + tp[1] * tp[1];
+            if constexpr (DIM == 3) pn += tp[DIM - 1] * tp[DIM - 1];
             c2[g] = 2.0f * kappa * pn + 1e-30f;
-            const float ax = -2.0f * tp[0], ay = -2.0f * tp[1];
+            const float ax = -2.0f * tp[0], ay = -2.0f * tp[1], az = -2.0f * pz[g];
             __bf16 ax1, ax2, ax3, ay1, ay2, ay3;
             split3(ax, ax1, ax2, ax3);
             split3(ay, ay1, ay2, ay3);
             const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
             const nn_bf16x8 lo = {ax1, ax1, ax2, ax1, ax2, ax3, ay1, ay1};
-            const nn_bf16x8 hi = {ay2, ay1, ay2, ay3, one, one, one, zero};
-            bfr[g] = half ? hi : lo;
+            if constexpr (DIM == 2) {
+                const nn_bf16x8 hi = {ay2, ay1, ay2, ay3, one, one, one, zero};
+                bfr[0][g] = half ? hi : lo;
+            } else {
+                __bf16 az1, az2, az3;
+                split3(az, az1, az2, az3);
+                const nn_bf16x8 hi = {ay2, ay1, ay2, ay3, az1, az1, az2, az1};
+                const nn_bf16x8 lo1 = {az2, az3, one, one, one, zero, zero, zero};
+                const nn_bf16x8 hi1 = {zero, zero, zero, zero, zero, zero, zero, zero};
+                bfr[0][g] = half ? hi : lo;
+                bfr[KS - 1][g] = half ? hi1 : lo1;
+            }
             // any e_j bounds the minimum: start from the previous iteration's correspondent (fp32 chain of the filter above)
             float b0 = INFINITY;
             dseed[g] = INFINITY;
@@ -503,10 +533,19 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                 const int j = prev_idx[(size_t)b * N + i];
                 if (j >= 0 && j < Mpad) {
                     const float jx = tb[j], jy = tb[(size_t)Mpad + j];
-                    const float jn = __builtin_fmaf(jy, jy, jx * jx);
-                    b0 = __builtin_fmaf(jx, ax, __builtin_fmaf(jy, ay, jn));
+                    float jz = 0.f;
+                    float jn = __builtin_fmaf(jy, jy, jx * jx);
+                    float e = 0.f;
+                    if constexpr (DIM == 3) {
+                        jz = tb[(size_t)2 * Mpad + j];
+                        jn = __builtin_fmaf(jz, jz, jn);
+                        e = __builtin_fmaf(jz, az, __builtin_fmaf(jy, ay, jn));
+                    } else {
+                        e = __builtin_fmaf(jy, ay, jn);
+                    }
+                    b0 = __builtin_fmaf(jx, ax, e);
                     b0 = (b0 == b0) ? b0 : INFINITY;
-                    const float dj = nn_dist<DIM>(jx, jy, 0.f, tp);       // the normative distance to the seed target
+                    const float dj = nn_dist<DIM>(jx, jy, jz, tp);       // the normative distance to the seed target
                     dseed[g] = (dj == dj) ? dj : INFINITY;
                     jseed[g] = j;
                 }
@@ -515,12 +554,13 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
             thr[g] = __builtin_fmaf(b0, kp1, c2[g]);
         }
         // ---- the two points this lane owns for the exact part
-        float pox[2], poy[2], cur[2], dso[2];
+        float pox[2], poy[2], poz[2], cur[2], dso[2];
         int pidx[2], jj[2], jso[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             pox[q] = half ? px[2 + q] : px[q];
             poy[q] = half ? py[2 + q] : py[q];
+            poz[q] = half ? pz[2 + q] : pz[q];
             pidx[q] = sb * NNM_PTS + wv * (NNM_GROUPS * 32) + (2 * half + q) * 32 + col;
             cur[q] = INFINITY;
             dso[q] = half ? dseed[2 + q] : dseed[q];
@@ -531,26 +571,58 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
         const int t1 = min(ntiles, t0 + tiles_per_unit);
         jj[0] = jj[1] = t0 * NN_TILE;
 
-        for (int t = t0; t < t1; ++t) {
+        for (int t = t0 * KS; t < t1 * KS; ++t) {          // sub-tiles of TT targets
             __syncthreads();
-            {   // stage: this thread's 4 targets -> the fp32 planes and rows 4 (tid % 8) .. + 3 of fragment tid / 8
-                const float4 vx = *reinterpret_cast<const float4 *>(tb + (size_t)t * NN_TILE + tid * 4);
-                const float4 vy = *reinterpret_cast<const float4 *>(tb + (size_t)Mpad + (size_t)t * NN_TILE + tid * 4);
-                *reinterpret_cast<float4 *>(&lt[0][tid * 4]) = vx;
-                *reinterpret_cast<float4 *>(&lt[1][tid * 4]) = vy;
-                const float xs[4] = {vx.x, vx.y, vx.z, vx.w}, ys[4] = {vy.x, vy.y, vy.z, vy.w};
-                uint4 *fr = &frag[tid >> 3][(tid & 7) * 4];
+            {   // stage: this thread's TPT targets -> the fp32 planes and rows TPT (tid % (32 / TPT)) .. of fragment tid / (32 / TPT)
+                float xs[TPT], ys[TPT], zs[TPT];
+                const int ch = tid / (32 / TPT), p4 = (tid % (32 / TPT)) * TPT;      // chunk, first target inside the chunk
+                const int lpos = ch * 32 + ((((p4 >> 2) ^ ((ch >> 1) & 7)) << 2) | (p4 & 3));
+                if constexpr (TPT == 4) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(tb + (size_t)t * TT + tid * 4);
+                    const float4 vy = *reinterpret_cast<const float4 *>(tb + (size_t)Mpad + (size_t)t * TT + tid * 4);
+                    *reinterpret_cast<float4 *>(&lt[0][lpos]) = vx;
+                    *reinterpret_cast<float4 *>(&lt[1][lpos]) = vy;
+                    xs[0] = vx.x; xs[1] = vx.y; xs[2] = vx.z; xs[3] = vx.w;
+                    ys[0] = vy.x; ys[1] = vy.y; ys[2] = vy.z; ys[3] = vy.w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float n = __builtin_fmaf(ys[r], ys[r], xs[r] * xs[r]);
+                    for (int r = 0; r < TPT; ++r) zs[r] = 0.f;
+                } else {
+                    const float2 vx = *reinterpret_cast<const float2 *>(tb + (size_t)t * TT + tid * 2);
+                    const float2 vy = *reinterpret_cast<const float2 *>(tb + (size_t)Mpad + (size_t)t * TT + tid * 2);
+                    const float2 vz = *reinterpret_cast<const float2 *>(tb + (size_t)(DIM - 1) * Mpad + (size_t)t * TT + tid * 2);
+                    *reinterpret_cast<float2 *>(&lt[0][lpos]) = vx;
+                    *reinterpret_cast<float2 *>(&lt[1][lpos]) = vy;
+                    *reinterpret_cast<float2 *>(&lt[DIM - 1][lpos]) = vz;
+                    xs[0] = vx.x; xs[TPT - 1] = vx.y;
+                    ys[0] = vy.x; ys[TPT - 1] = vy.y;
+                    zs[0] = vz.x; zs[TPT - 1] = vz.y;
+                }
+                uint4 *fr = &frag[0][ch][p4];
+#pragma unroll
+                for (int r = 0; r < TPT; ++r) {
+                    float n = __builtin_fmaf(ys[r], ys[r], xs[r] * xs[r]);
+                    if constexpr (DIM == 3) n = __builtin_fmaf(zs[r], zs[r], n);
                     __bf16 x1, x2, x3, y1, y2, y3, n1, n2, n3;
                     split3(xs[r], x1, x2, x3);
                     split3(ys[r], y1, y2, y3);
                     split3(n, n1, n2, n3);
                     const nn_bf16x8 lo = {x1, x2, x1, x3, x2, x1, y1, y2};
-                    const nn_bf16x8 hi = {y1, y3, y2, y1, n1, n2, n3, (__bf16)0.0f};
                     fr[r] = __builtin_bit_cast(uint4, lo);
-                    fr[32 + r] = __builtin_bit_cast(uint4, hi);
+                    if constexpr (DIM == 2) {
+                        const nn_bf16x8 hi = {y1, y3, y2, y1, n1, n2, n3, (__bf16)0.0f};
+                        fr[32 + r] = __builtin_bit_cast(uint4, hi);
+                    } else {
+                        __bf16 z1, z2, z3;
+                        split3(zs[r], z1, z2, z3);
+                        const __bf16 zero = (__bf16)0.0f;
+                        const nn_bf16x8 hi = {y1, y3, y2, y1, z1, z2, z1, z3};
+                        const nn_bf16x8 lo1 = {z2, z1, n1, n2, n3, zero, zero, zero};
+                        const nn_bf16x8 hi1 = {zero, zero, zero, zero, zero, zero, zero, zero};
+                        fr[32 + r] = __builtin_bit_cast(uint4, hi);
+                        uint4 *fr1 = &frag[KS - 1][ch][p4];
+                        fr1[r] = __builtin_bit_cast(uint4, lo1);
+                        fr1[32 + r] = __builtin_bit_cast(uint4, hi1);
+                    }
                 }
             }
             __syncthreads();
@@ -575,28 +647,42 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                 brun[g] = __builtin_fminf(brun[g], t);
                 if (refresh) thr[g] = __builtin_fmaf(brun[g], kp1, c2[g]);
             };
-            uint4 af_next = frag[0][lane];
+            uint4 af_next[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) af_next[k] = frag[k][0][lane];
 #pragma unroll 2
-            for (int c = 0; c < NN_TILE / 32; ++c) {
-                const nn_bf16x8 af = __builtin_bit_cast(nn_bf16x8, af_next);
-                af_next = frag[(c + 1) & (NN_TILE / 32 - 1)][lane];          // next chunk's fragment in flight behind this chunk's MFMAs
+            for (int c = 0; c < NCH; ++c) {
+                nn_bf16x8 af[KS];
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    af[k] = __builtin_bit_cast(nn_bf16x8, af_next[k]);
+                    af_next[k] = frag[k][(c + 1) & (NCH - 1)][lane];            // next chunk's fragment in flight behind this chunk's MFMAs
+                }
                 const bool refresh = (c & 1) != 0;
-                // two MFMAs in flight per wave (32 accumulator registers: 4 waves per SIMD)
+                // two (chains of) MFMAs in flight per wave (32 accumulator registers)
 #pragma unroll
                 for (int h2 = 0; h2 < NNM_GROUPS; h2 += 2) {
-                    const nn_f32x16 acc0 = mfma_32x32x16_bf16_c0(af, bfr[h2]);
-                    const nn_f32x16 acc1 = mfma_32x32x16_bf16_c0(af, bfr[h2 + 1]);
+                    nn_f32x16 acc0 = mfma_32x32x16_bf16_c0(af[0], bfr[0][h2]);
+                    nn_f32x16 acc1 = mfma_32x32x16_bf16_c0(af[0], bfr[0][h2 + 1]);
+                    if constexpr (KS == 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[KS - 1], bfr[KS - 1][h2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[KS - 1], bfr[KS - 1][h2 + 1], acc1, 0, 0, 0);
+                    }
                     reduce(acc0, h2, refresh);
                     reduce(acc1, h2 + 1, refresh);
                 }
             }
-            // ---- flags of the two lanes that share a point, then the exact re-scan of this tile's flagged chunks while
-            // the tile is in LDS (chunks ascending, tiles ascending, strict '<': the lowest index among equal distances)
+            // ---- flags of the two lanes that share a point, then the exact re-scan of this sub-tile's flagged chunks while
+            // it is in LDS (chunks ascending, tiles ascending, strict '<': the lowest index among equal distances)
             unsigned wo[2];
             {
                 unsigned wf[NNM_GROUPS];
 #pragma unroll
-                for (int g = 0; g < NNM_GROUPS; ++g) wf[g] = w[g] | (unsigned)__shfl_xor((int)w[g], 32, 64);
+                for (int g = 0; g < NNM_GROUPS; ++g) {
+                    // (NCH < 32: the flags sit in the top NCH bits, in chunk order from bit 31 down, once the word has been shifted NCH times)
+                    const unsigned wg = NCH == 32 ? w[g] : (w[g] << (32 - NCH));
+                    wf[g] = wg | (unsigned)__shfl_xor((int)wg, 32, 64);
+                }
                 wo[0] = half ? wf[2] : wf[0];
                 wo[1] = half ? wf[3] : wf[1];
             }
@@ -610,22 +696,27 @@ __global__ __launch_bounds__(NN_THREADS, 4) void nn_mfma_kernel(
                     const unsigned rest = ww & ~(0x80000000u >> c);
                     wo[0] = second ? wo[0] : rest;
                     wo[1] = second ? rest : wo[1];
-                    const float pq[DIM] = {second ? pox[1] : pox[0], second ? poy[1] : poy[0]};
-                    const int o0 = c * 32;
+                    float pq[DIM];
+                    pq[0] = second ? pox[1] : pox[0];
+                    pq[1] = second ? poy[1] : poy[0];
+                    if constexpr (DIM == 3) pq[DIM - 1] = second ? poz[1] : poz[0];
+                    const int o0 = c * 32, sw = ((c >> 1) & 7) * 4;
                     float best = INFINITY;
                     int bj = 0;
 #pragma unroll
                     for (int h = 0; h < 8; ++h) {
-                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
-                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
-                        const float d0 = nn_dist<DIM>(vx.x, vy.x, 0.f, pq), d1 = nn_dist<DIM>(vx.y, vy.y, 0.f, pq);
-                        const float d2 = nn_dist<DIM>(vx.z, vy.z, 0.f, pq), d3 = nn_dist<DIM>(vx.w, vy.w, 0.f, pq);
+                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + ((h * 4) ^ sw)]);
+                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + ((h * 4) ^ sw)]);
+                        float4 vz = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (DIM == 3) vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][o0 + ((h * 4) ^ sw)]);
+                        const float d0 = nn_dist<DIM>(vx.x, vy.x, vz.x, pq), d1 = nn_dist<DIM>(vx.y, vy.y, vz.y, pq);
+                        const float d2 = nn_dist<DIM>(vx.z, vy.z, vz.z, pq), d3 = nn_dist<DIM>(vx.w, vy.w, vz.w, pq);
                         if (d0 < best) { best = d0; bj = h * 4 + 0; }
                         if (d1 < best) { best = d1; bj = h * 4 + 1; }
                         if (d2 < best) { best = d2; bj = h * 4 + 2; }
                         if (d3 < best) { best = d3; bj = h * 4 + 3; }
                     }
-                    const int jn = t * NN_TILE + o0 + bj;
+                    const int jn = t * TT + o0 + bj;
                     if (!second && best < cur[0]) { cur[0] = best; jj[0] = jn; }
                     if (second && best < cur[1]) { cur[1] = best; jj[1] = jn; }
                 }
@@ -1517,7 +1608,7 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
     int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, P, ucap;
-    bool mfma;      // dim 2: the filter runs on the matrix cores (nn_mfma_kernel)
+    bool mfma;      // the filter runs on the matrix cores (nn_mfma_kernel)
 };
 
 
@@ -1539,7 +1630,7 @@ NNPlan nn_plan(int B, int N, int M, int dim)
     pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
-    pl.mfma = dim == 2 && use_nn_mfma();
+    pl.mfma = use_nn_mfma();
     // Vector-pipe filter: single tiles -- short ranges balance the CUs better, and a range without candidates below the starting
     // bound costs no atomic (5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch).  Matrix-core filter: a lane's
     // running bound restarts with every unit, and without a seed (the first ICP iteration) every restart flags a "record"
@@ -1553,7 +1644,7 @@ NNPlan nn_plan(int B, int N, int M, int dim)
     pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
     // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs); 3 of the matrix-core
     // kernel's (40 KB of LDS each, <= 128 VGPRs)
-    pl.grid = std::min(pl.total_units, pl.mfma ? 1024 : 2048);
+    pl.grid = std::min(pl.total_units, pl.mfma ? (dim == 2 ? 1024 : 768) : 2048);
     return pl;
 }
 
@@ -1591,6 +1682,9 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
     if (pl.mfma && dim == 2) {
         hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist, ucnt,
                            pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 360.0f * U, packed);
+    } else if (pl.mfma) {
+        hipLaunchKernelGGL((nn_mfma_kernel<3>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist, ucnt,
+                           pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 496.0f * U, packed);
     } else if (dim == 2) {
         hipLaunchKernelGGL((nn_prefilter_kernel<2, 2, 16>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist,
                            ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 48.0f * U, packed);
