@@ -60,19 +60,36 @@ extern "C" int mmk_host_read_rows(const char *path, int64_t header_bytes, int32_
             (sh > 0 && !read_all(out, (size_t)sh * row_bytes, (size_t)header_bytes + head)))
             rc = MMK_ERR_ARG;
     } else {
-        // column cut: one read into a per-thread scratch (no mmap: mapping and faulting take the process-wide mm lock, which
-        // serialises the loader's threads), then one memcpy per row
-        static thread_local std::vector<char> scratch;
-        const size_t total = (size_t)rows * row_bytes;
-        if (scratch.size() < total) scratch.resize(total);
-        if (!read_all(scratch.data(), total, (size_t)header_bytes)) {
-            rc = MMK_ERR_ARG;
-        } else {
-            const char *src = scratch.data() + col0;
-            for (int r = 0; r < rows; ++r) {
+        // column cut.  A narrow cut (the 2-byte encoder column of a Navtech row: 800 bytes out of 1.3 MB) reads just its bytes,
+        // one pread per row; a wide one (the 3 360 power bytes behind the 11-byte row header) reads the rows in blocks of <= 256 KB
+        // into a buffer on this call's stack frame and copies the cut out of it -- no mmap (mapping and faulting take the
+        // process-wide mm lock, which serialises the loader's threads) and no per-thread heap buffer that the batch call's
+        // short-lived threads would allocate and fault in again for every batch.
+        if ((size_t)ncols * 8 <= (size_t)row_bytes) {
+            for (int r = 0; r < rows && rc == MMK_OK; ++r) {
                 int d = r + sh;
                 if (d >= rows) d -= rows;
-                memcpy(out + (size_t)d * ncols, src + (size_t)r * row_bytes, (size_t)ncols);
+                if (!read_all(out + (size_t)d * ncols, (size_t)ncols, (size_t)header_bytes + (size_t)r * row_bytes + (size_t)col0)) rc = MMK_ERR_ARG;
+            }
+        } else {
+            constexpr size_t BLOCK = 256 * 1024;
+            char buf[BLOCK];
+            const int rows_per = (int)std::max<size_t>(1, BLOCK / (size_t)row_bytes);
+            if ((size_t)row_bytes > BLOCK) {
+                mmk::set_error("mmk_host_read_rows: rows of %d bytes are longer than the %zu-byte staging block", row_bytes, BLOCK);
+                rc = MMK_ERR_ARG;
+            }
+            for (int r0 = 0; r0 < rows && rc == MMK_OK; r0 += rows_per) {
+                const int nr = std::min(rows_per, rows - r0);
+                if (!read_all(buf, (size_t)nr * row_bytes, (size_t)header_bytes + (size_t)r0 * row_bytes)) {
+                    rc = MMK_ERR_ARG;
+                    break;
+                }
+                for (int r = 0; r < nr; ++r) {
+                    int d = r0 + r + sh;
+                    if (d >= rows) d -= rows;
+                    memcpy(out + (size_t)d * ncols, buf + (size_t)r * row_bytes + col0, (size_t)ncols);
+                }
             }
         }
     }

@@ -246,6 +246,13 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         m = load_xyz_bin(os.path.join(pdir, "map", "%d.bin" % map_stamp), 6)
         return raw, filt, np.ascontiguousarray(m[:, :3]), np.ascontiguousarray(m[:, 3:6])
 
+    def _cloud_sources(self, index):
+        """The export's cloud files of sample ``index`` (what _read_clouds opens)."""
+        pair_idx, loc_stamp, map_stamp = self.samples[index]
+        pdir = self.pair_dirs[pair_idx]
+        return [os.path.join(pdir, "scan", "%d_raw.bin" % loc_stamp), os.path.join(pdir, "scan", "%d_filt.bin" % loc_stamp),
+                os.path.join(pdir, "map", "%d.bin" % map_stamp)]
+
     @staticmethod
     def _to_sensor_frame(map_pts, map_norms, T):
         return (T[:3, :3] @ map_pts.T + T[:3, 3:4]).T, (T[:3, :3] @ map_norms.T).T       # :387-388
@@ -341,7 +348,23 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         epoch) -- written on first use next to the export."""
         pair_idx, loc_stamp, map_stamp = self.samples[index]
         pdir = os.path.join(self.pair_dirs[pair_idx], "prepared")
-        path = os.path.join(pdir, "%d_%d_%d_%d_%d.f32" % (loc_stamp, map_stamp, self.max_loc_pts, self.max_map_pts, int(self.gt_eye)))
+        # the file name carries a digest of EVERYTHING load_graph_data's result depends on besides the sample's stamps: padding
+        # sizes and value, sensors (filter_map), gt_eye, float type, the ground-truth pose, the sensor-robot transform, and
+        # size + mtime of the source cloud files -- a changed configuration or re-exported data gets a new file instead of
+        # stale clouds (ADVICE r03)
+        import hashlib
+        h = hashlib.sha1()
+        h.update(repr((self.max_loc_pts, self.max_map_pts, float(self.target_pad_val), self.loc_sensor, self.map_sensor, bool(self.gt_eye),
+                       str(self.float_type))).encode())
+        h.update(self.T_loc_gt[index].to(torch.float64).contiguous().numpy().tobytes())
+        h.update(self.T_map_sensor_robot[pair_idx].to(torch.float64).contiguous().numpy().tobytes())
+        for src in self._cloud_sources(index):
+            try:
+                st = os.stat(src)
+                h.update(("%s:%d:%d" % (os.path.basename(src), st.st_size, st.st_mtime_ns)).encode())
+            except OSError:
+                h.update(("%s:missing" % os.path.basename(src)).encode())
+        path = os.path.join(pdir, "%d_%d_%s.f32" % (loc_stamp, map_stamp, h.hexdigest()[:16]))
         if not os.path.exists(path):
             raw, filt, mp, _, _ = self.load_graph_data(index, self.T_loc_gt[index])
             os.makedirs(pdir, exist_ok=True)
@@ -363,14 +386,16 @@ class ICPWeightDataset(torch.utils.data.Dataset):
                 "map_data": {"pc": ((self.max_map_pts, 6), f), "timestamp": ((), torch.int64)},
                 "transforms": {"T_ml_init": ((4, 4), f), "T_ml_gt": ((4, 4), f)}}
 
-    def fill_batch(self, indices, bufs, threads=4):
+    def fill_batch(self, indices, bufs, threads=4, generator=None):
         """Items ``indices`` written into rows 0.. of the batch buffers ``bufs`` (native_item_spec's layout): the same items as
         ``__getitem__`` of the ``batched_prepare`` mode, except that the augmentation's rotation of the clouds is left to the
         device (``aug_cs`` = (cos, sin) of the drawn yaw; finish_batch applies it).  ONE interpreter thread: the per-item share
         that needs Python (paths and caches resolved once per sample, the 400 encoder counts -> azimuths in numpy, the
         augmentation's yaw drawn in item order -- reproducible under a seed, which a pool of worker threads is not) runs
         here; every byte of the tensors is then moved by one mmk_host_read_rows_batch call whose ``threads`` C threads share
-        the jobs (page cache -> pinned memory, column cut and azimuth roll on the way; GIL released for the whole batch)."""
+        the jobs (page cache -> pinned memory, column cut and azimuth roll on the way; GIL released for the whole batch).
+        ``generator``: the torch.Generator the yaw is drawn from (DeviceLoader passes its own, so that the draws do not
+        interleave with whatever the training thread takes from the global generator; None = the global one)."""
         from . import _lib
         L = _lib.lib()
         rd = L.mmk_host_read_rows
@@ -399,7 +424,7 @@ class ICPWeightDataset(torch.utils.data.Dataset):
             az = (enc.view(np.uint16).reshape(A) * (2 * np.pi / 5600)).astype(np.float32)
             shift, c, s = 0, 1.0, 0.0
             if self.augment:
-                angle = 2 * np.pi * torch.rand(1, dtype=self.float_type)
+                angle = 2 * np.pi * torch.rand(1, dtype=self.float_type, generator=generator)
                 c, s = float(torch.cos(angle)), float(torch.sin(angle))
                 az = az - np.float32(angle.item())
                 az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
@@ -512,7 +537,7 @@ class DeviceLoader:
     which the thread mode leaves to the device (tests/test_round3_cpu.py, tests/test_gpu_round3.py)."""
 
     def __init__(self, dataset, batch_size, device, num_workers=4, shuffle=False, drop_last=False, prefetch_factor=2,
-                 persistent_workers=True, mode="threads", passes=1):
+                 persistent_workers=True, mode="threads", passes=1, seed=None):
         if not getattr(dataset, "batched_prepare", False):
             raise ValueError("DeviceLoader needs a Dataset built with params['batched_prepare'] = True (CPU-only items)")
         if mode not in ("threads", "processes"):
@@ -532,6 +557,11 @@ class DeviceLoader:
                                                       drop_last=drop_last, pin_memory=self.device.type == "cuda", **kw)
         self._side = None
         self._bufs = {}            # (slot, batch length) -> pinned batch buffers
+        # the loader's own random stream (shuffle order, augmentation yaws), seeded once from the global seed: the producer
+        # thread's draws do not interleave with the training thread's draws from the global generator, so a seeded run gives
+        # the same batches whatever the timing
+        self._gen = torch.Generator()
+        self._gen.manual_seed(int(torch.initial_seed()) if seed is None else int(seed))
 
     def __len__(self):
         n = len(self.dataset)
@@ -541,7 +571,7 @@ class DeviceLoader:
     def _batches(self):
         n = len(self.dataset)
         for _ in range(self.passes):
-            order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+            order = torch.randperm(n, generator=self._gen).tolist() if self.shuffle else list(range(n))
             for i in range(0, n, self.batch_size):
                 idx = order[i:i + self.batch_size]
                 if len(idx) < self.batch_size and self.drop_last:
@@ -558,7 +588,7 @@ class DeviceLoader:
             self._bufs[key] = bufs
         # one interpreter thread, num_workers C threads (fill_batch); the Python worker pool of the first cut made the
         # training thread wait for the interpreter lock
-        self.dataset.fill_batch(idx, bufs, threads=self.num_workers)
+        self.dataset.fill_batch(idx, bufs, threads=self.num_workers, generator=self._gen)
         return bufs
 
     N_SLOTS = 4          # pinned batch buffers: one being filled, up to two queued, one being copied to the device

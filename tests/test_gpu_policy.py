@@ -93,7 +93,9 @@ def test_unet_hip_backend_golden(golden_dir, tag):
     assert np.all(np.isfinite(ga))
     # bf16 storage of 33 layers of activations and gradient tensors at random init (small, noisy gradients):
     # direction and size per tensor, global relative error (measured values in DESIGN.md)
-    _check_grads_against_golden(model, gv, tag, names, cos_min=0.90 if tag == "a" else 0.85, rel_max=0.15)
+    # bounds = what the build measures (a: 4.5 % / cosine 0.928, b: 4.8 % / 0.872; round 4, deterministic: dropout is off) with
+    # 30 % of margin on the error (relative L2 x 1.3, 1 - cosine x 1.3)
+    _check_grads_against_golden(model, gv, tag, names, cos_min=0.906 if tag == "a" else 0.833, rel_max=0.059 if tag == "a" else 0.062)
 
 
 def test_unet_hip_golden_640(golden_dir):
@@ -119,7 +121,7 @@ def test_unet_hip_golden_640(golden_dir):
     gsel = torch.from_numpy(np.random.default_rng(197).normal(size=(1, H, H)).astype(np.float32)).to(DEV)
     (m * gsel).sum().backward()
     names = [str(n) for n in gv["names_c"]]
-    _check_grads_against_golden(model, gv, "c", names, cos_min=0.90, rel_max=0.15)
+    _check_grads_against_golden(model, gv, "c", names, cos_min=0.903, rel_max=0.088)       # measured 6.8 % / 0.926, + 30 %
     gp = dict(model.named_parameters())
     for key, name in (("g_enc00_w_c", "encoder.0.0.weight"), ("g_enc00_b_c", "encoder.0.0.bias"),
                       ("g_final_w_c", "final_layer.0.weight"), ("g_final_b_c", "final_layer.0.bias")):
@@ -287,9 +289,11 @@ def test_polar_network_golden(golden_dir, tag):
     ga = np.array([grads[k].grad.double().abs().sum().item() for k in names])
     assert np.all(np.isfinite(ga))
     # per-tensor gradient vectors of the reference module (unet_grads.npz).  50 x 84 shrinks to 1 x 2 pixels at the
-    # bottom of the network: its deep tensors average over a handful of bf16 values, hence the wider budget
+    # bottom of the network: its deep tensors average over a handful of bf16 values.  Bounds = measured (p: 9.1 % / cosine
+    # 0.952; q, with the range channel: 16.5 % / 0.793) + 30 % on the error; that the budget is rounding and not a per-level
+    # scaling error is what test_gpu_unet_kernels.py::test_unet_hip_backward_exact_on_pinned_activations checks at 50 x 84, tensor by tensor
     gv = np.load(os.path.join(golden_dir, "unet_grads.npz"), allow_pickle=False)
-    _check_grads_against_golden(model, gv, tag, names, cos_min=0.75, rel_max=0.25)
+    _check_grads_against_golden(model, gv, tag, names, cos_min=0.938 if tag == "p" else 0.731, rel_max=0.118 if tag == "p" else 0.214)
 
 
 def test_polar_network_train_step():

@@ -111,6 +111,43 @@ def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path
     wrk0.T_loc_init = ref0.T_loc_init.clone()
     got = next(iter(ds.DeviceLoader(wrk0, batch_size=2, device="cpu", num_workers=3)))
     _same(torch.utils.data.default_collate([ref0[0], ref0[1]]), got)
+    # the prepared-cloud cache is keyed on everything the clouds depend on: another padding value (or re-exported cloud files)
+    # gets clouds of its own instead of the stale file
+    n_before = len(os.listdir(os.path.join(wrk0.pair_dirs[0], "prepared")))
+    wrk1 = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
+    wrk1.T_loc_init = ref0.T_loc_init.clone()
+    wrk1.target_pad_val = 500.0
+    got1 = next(iter(ds.DeviceLoader(wrk1, batch_size=2, device="cpu", num_workers=2)))
+    pad_rows = got["map_data"]["pc"][..., 0] == wrk0.target_pad_val
+    assert pad_rows.any() and bool((got1["map_data"]["pc"][..., 0][pad_rows] == 500.0).all())
+    assert len(os.listdir(os.path.join(wrk1.pair_dirs[0], "prepared"))) > n_before
+    src = wrk0._cloud_sources(0)[2]
+    before = wrk0._prepared_clouds(0)
+    os.utime(src, ns=(os.stat(src).st_atime_ns, os.stat(src).st_mtime_ns + 10 ** 9))
+    wrk2 = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
+    assert wrk2._prepared_clouds(0) != before
+
+
+def test_device_loader_draws_from_its_own_generator(golden_dir, tmp_path):
+    """Shuffle order and augmentation yaws come from the loader's private generator: the same seed gives the same batches
+    whatever is drawn from the global generator in between (the training thread draws from it concurrently)."""
+    g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
+    pairs = _write_export(str(tmp_path), g)
+    dset = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
+
+    def run(noise):
+        out = []
+        for b in ds.DeviceLoader(dset, batch_size=1, device="cpu", num_workers=2, shuffle=True, seed=77):
+            out.append(b)
+            if noise:
+                torch.rand(5)
+        return out
+    torch.manual_seed(1)
+    a = run(False)
+    torch.manual_seed(2)
+    b = run(True)
+    for x, y in zip(a, b):
+        _same(x, y)
 
 
 def test_host_read_rows_roll_and_columns(tmp_path):
