@@ -402,11 +402,13 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         loc, mp, tr = bufs["loc_data"], bufs["map_data"], bufs["transforms"]
         A, R = loc["fft_u8"].shape[1], loc["fft_u8"].shape[2]
         nb_scan, nb_map = self.max_loc_pts * 12, self.max_map_pts * 24
-        jobs = (_lib.ReadJob * (5 * len(indices)))()
-        keep = []                                      # (the path bytes must outlive the call)
+        nb = len(indices)
+        jobs = (_lib.ReadJob * (5 * nb))()
+        keep = []                                      # (the path bytes must outlive the calls)
         az_all, cs_all = loc["azimuths"].numpy(), loc["aug_cs"].numpy()
-        enc = np.empty((A, 2), np.uint8)
-        n = 0
+        # ---- pass 1 (one library call for the batch): the 2-byte encoder column of every item's radar rows
+        enc = np.empty((nb, A, 2), np.uint8)
+        infos = []
         for j, index in enumerate(indices):
             info = self._native_info.get(index)
             if info is None:
@@ -417,38 +419,49 @@ class ICPWeightDataset(torch.utils.data.Dataset):
                         self._decoded(png)
                 info = ((rpath + ".u8").encode(), (cpath + ".u8").encode(), self._prepared_clouds(index).encode())
                 self._native_info[index] = info
-            rfile, cfile, prep = info
+            infos.append(info)
             keep.append(info)
-            if rd(rfile, 8, A, R + 11, 8, 2, 0, enc.ctypes.data) != 0:
-                raise _lib.MmkError(L.mmk_last_error().decode())
-            az = (enc.view(np.uint16).reshape(A) * (2 * np.pi / 5600)).astype(np.float32)
-            shift, c, s = 0, 1.0, 0.0
-            if self.augment:
-                angle = 2 * np.pi * torch.rand(1, dtype=self.float_type, generator=generator)
-                c, s = float(torch.cos(angle)), float(torch.sin(angle))
-                az = az - np.float32(angle.item())
-                az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
-                shift = -int(np.argmin(az))
-                az = np.roll(az, shift)
-            az_all[j] = az
-            cs_all[j, 0], cs_all[j, 1] = c, s
-
-            def dst(t):
-                return t.data_ptr() + j * t.stride(0) * t.element_size()
-            for (path, hdr, rows, rb, c0, nc, roll, d) in (
-                    (rfile, 8, A, R + 11, 11, R, shift, dst(loc["fft_u8"])),
-                    (cfile, 8, A, R, 0, R, shift, dst(loc["cfar_u8"])),
-                    (prep, 0, 1, nb_scan, 0, nb_scan, 0, dst(loc["raw_pc"])),
-                    (prep, nb_scan, 1, nb_scan, 0, nb_scan, 0, dst(loc["filtered_pc"])),
-                    (prep, 2 * nb_scan, 1, nb_map, 0, nb_map, 0, dst(mp["pc"]))):
+            q = jobs[j]
+            q.path, q.header_bytes, q.rows, q.row_bytes, q.col0, q.ncols, q.roll, q.dst = info[0], 8, A, R + 11, 8, 2, 0, enc[j].ctypes.data
+        if L.mmk_host_read_rows_batch(jobs, nb, int(threads)) != 0:
+            raise _lib.MmkError(L.mmk_last_error().decode())
+        # ---- the interpreter's share, vectorised over the batch: encoder counts -> azimuths, the augmentation's yaw (drawn in
+        # item order from one call), the roll that brings the smallest azimuth to row 0 (augment_data, icp_weight_dataset.py:425-452)
+        az = (enc.reshape(nb, A * 2).view(np.uint16).reshape(nb, A) * (2 * np.pi / 5600)).astype(np.float32)
+        shifts = np.zeros(nb, np.int64)
+        cs_all[:nb, 0], cs_all[:nb, 1] = 1.0, 0.0
+        if self.augment:
+            angles = 2 * np.pi * torch.rand(nb, dtype=self.float_type, generator=generator)
+            cs_all[:nb, 0], cs_all[:nb, 1] = torch.cos(angles).numpy(), torch.sin(angles).numpy()
+            az = az - angles.numpy().astype(np.float32)[:, None]
+            az = np.where(az < 0.0, az + np.float32(2 * np.pi), az)
+            shifts = -np.argmin(az, axis=1)
+            rows = (np.arange(A)[None, :] - shifts[:, None]) % A          # np.roll(az[j], shifts[j]) for every j
+            az = np.take_along_axis(az, rows, axis=1)
+        az_all[:nb] = az
+        # ---- pass 2: every byte of the tensors
+        n = 0
+        ts_loc, ts_map = loc["timestamp"].numpy(), mp["timestamp"].numpy()
+        Ti, Tg = tr["T_ml_init"].numpy(), tr["T_ml_gt"].numpy()
+        strides = [(t.data_ptr(), t.stride(0) * t.element_size()) for t in (loc["fft_u8"], loc["cfar_u8"], loc["raw_pc"], loc["filtered_pc"], mp["pc"])]
+        for j, index in enumerate(indices):
+            rfile, cfile, prep = infos[j]
+            shift = int(shifts[j])
+            for k, (path, hdr, rows_, rb, c0, nc, roll) in enumerate((
+                    (rfile, 8, A, R + 11, 11, R, shift),
+                    (cfile, 8, A, R, 0, R, shift),
+                    (prep, 0, 1, nb_scan, 0, nb_scan, 0),
+                    (prep, nb_scan, 1, nb_scan, 0, nb_scan, 0),
+                    (prep, 2 * nb_scan, 1, nb_map, 0, nb_map, 0))):
                 q = jobs[n]
-                q.path, q.header_bytes, q.rows, q.row_bytes, q.col0, q.ncols, q.roll, q.dst = path, hdr, rows, rb, c0, nc, roll, d
+                q.path, q.header_bytes, q.rows, q.row_bytes, q.col0, q.ncols, q.roll = path, hdr, rows_, rb, c0, nc, roll
+                q.dst = strides[k][0] + j * strides[k][1]
                 n += 1
             _, loc_stamp, map_stamp = self.samples[index]
-            loc["timestamp"].numpy()[j] = loc_stamp
-            mp["timestamp"].numpy()[j] = map_stamp
-            tr["T_ml_init"].numpy()[j] = self.T_loc_init[index].numpy()
-            tr["T_ml_gt"].numpy()[j] = self.T_loc_gt[index].numpy()
+            ts_loc[j] = loc_stamp
+            ts_map[j] = map_stamp
+            Ti[j] = self.T_loc_init[index].numpy()
+            Tg[j] = self.T_loc_gt[index].numpy()
         if L.mmk_host_read_rows_batch(jobs, n, int(threads)) != 0:
             raise _lib.MmkError(L.mmk_last_error().decode())
         del keep
@@ -601,9 +614,16 @@ class DeviceLoader:
             yield from self.loader
             return
         import queue
+        import sys
         q = queue.Queue(maxsize=2)
         self._free = threading.Semaphore(self.N_SLOTS)
         stop = threading.Event()
+        # The producer runs interpreter code too (a few hundred microseconds per batch); with CPython's default 5 ms switch
+        # interval the training thread, which needs the interpreter lock ~300 times per step, can wait up to 5 ms for it
+        # whenever the producer happens to hold it -- longer than the launch queue stays fed.  0.5 ms hands the lock over
+        # quickly; restored when the iteration ends.
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 5e-4))
 
         def produce():
             try:
@@ -628,6 +648,7 @@ class DeviceLoader:
                     raise item
                 yield item
         finally:
+            sys.setswitchinterval(old_switch)
             stop.set()
             while th.is_alive():                      # unblock a producer waiting on a full queue
                 try:

@@ -50,7 +50,7 @@ def test_device_loader_equals_default_items(golden_dir, tmp_path, mode):
 
 def test_loader_throughput_against_step_rate(tmp_path):
     """Full-size export (400 x 3371 Navtech PNG rows, 5 120-row scan clouds, 20 480-row maps): what the loader delivers per
-    second next to what the training step consumes at B = 32.  The numbers go to gpurun_out/r03_loader.json; the assertion is
+    second next to what the training step consumes at B = 32.  The numbers go to gpurun_out/r04_loader.json; the assertion is
     that a step fed by the loader (staging overlapped on the side stream) trains on the loader's batches and that the
     loader's rate is reported -- whether it keeps up depends on the host (it is memcpy-bound: ~3.3 MB per item)."""
     import export_util
@@ -93,6 +93,25 @@ def test_loader_throughput_against_step_rate(tmp_path):
             loss, _ = trn.train_step(model, b, opt, lw, DEV)
     torch.cuda.synchronize()
     res["step_pairs_per_s_resident_batches"] = 5 * len(batches) * B / (time.time() - t0)
+    # the same steps with the loader's device work in front of each of them, NOT overlapped: host batch (pinned) -> copies,
+    # bytes -> floats, polar -> Cartesian (finish_batch) on the step's own stream, then the step.  This is the GPU work a
+    # loader-fed step consists of; the resident number above leaves the staging out altogether.
+    cpu_batches = []
+    spec = d.native_item_spec()
+    for k in range(2):
+        bufs = {grp: {kk: torch.empty((B,) + tuple(shape), dtype=dt, pin_memory=len(shape) > 0) for kk, (shape, dt) in dd.items()}
+                for grp, dd in spec.items()}
+        d.fill_batch(list(range(k * B, (k + 1) * B)), bufs, threads=8)
+        cpu_batches.append(bufs)
+    for cb in cpu_batches:
+        trn.train_step(model, ds.finish_batch(cb, DEV, d.network_input_type, d.float_type, d.polar_res), opt, lw, DEV)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for rep in range(5):
+        for cb in cpu_batches:
+            loss, _ = trn.train_step(model, ds.finish_batch(cb, DEV, d.network_input_type, d.float_type, d.polar_res), opt, lw, DEV)
+    torch.cuda.synchronize()
+    res["step_pairs_per_s_resident_plus_staging_serial"] = 5 * len(cpu_batches) * B / (time.time() - t0)
     # 16 passes over the 64 items in one iteration (32 batches, the pipeline stays full across the passes as it does over a
     # real epoch; restarting the iterator every 2 batches would time the pipeline's fill, not its rate)
     for nw in (4, 8):
@@ -110,13 +129,19 @@ def test_loader_throughput_against_step_rate(tmp_path):
     assert torch.isfinite(loss)
     try:
         os.makedirs(OUT, exist_ok=True)
-        json.dump(res, open(os.path.join(OUT, "r03_loader.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(OUT, "r04_loader.json"), "w"), indent=1)
     except OSError:
         pass
     print(res)
     # fed by the loader the step runs at the slower of the two rates (staging overlaps the step)
     best = max(v for k, v in res.items() if k.startswith("loader_items_per_s"))
-    assert res["train_pairs_per_s_fed_by_loader"] > 0.6 * min(res["loader_items_per_s_threads_8"], res["step_pairs_per_s_resident_batches"]), res
+    # (round 4: the bound was 0.6; with the producer's interpreter share vectorised and the interpreter's switch interval
+    # shortened while a loader iterates, the fed step is expected within 5 % of the resident one -- asserted at 0.9 for the
+    # host-to-host spread of the pool)
+    floor = 0.85 * min(res["loader_items_per_s_threads_8"], res["step_pairs_per_s_resident_batches"])
+    assert res["train_pairs_per_s_fed_by_loader"] > floor and res["train_pairs_per_s_fed_by_loader_threads_4"] > floor, res
+    # ... and at least 95 % of what the same GPU work takes without any overlap
+    assert res["train_pairs_per_s_fed_by_loader"] > 0.95 * res["step_pairs_per_s_resident_plus_staging_serial"], res
     assert best > 0
 
 
