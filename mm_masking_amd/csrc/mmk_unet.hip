@@ -738,7 +738,9 @@ struct DeepCfg {
     static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16) + BM * sizeof(float);   // (+ the bias)
 };
 
-template <int BM, int NT, bool LK = false>
+// SUBW: the packed weights are laid out for blocks of a.wpack_mtb 16-channel tiles (a wider BM); this block's BM channels are a
+// slice of one such group (the tail launches of dispatch_conv_deep's sub-batch split)
+template <int BM, int NT, bool LK = false, bool SUBW = false>
 __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
     using C = DeepCfg<BM, NT>;
@@ -796,11 +798,23 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         }
     };
     auto load_w = [&](int chunk) {
-        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NW * 8);
+        if constexpr (SUBW) {
+            const int pm = a.wpack_mtb, per = pm / MTB;           // tiles per packed group, kernel groups per packed group
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)((group / per) * nchunk + chunk)) * NS * pm * 512);
+            const int m_off = (group % per) * MTB;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const int g = tid + i * DEEP_THREADS;
-            rw[i] = wsrc[g < NW ? g : NW - 1];
+            for (int i = 0; i < RW; ++i) {
+                int g = tid + i * DEEP_THREADS;
+                g = g < NW ? g : NW - 1;
+                rw[i] = wsrc[((g / (MTB * 64)) * pm + m_off) * 64 + g % (MTB * 64)];
+            }
+        } else {
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NW * 8);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const int g = tid + i * DEEP_THREADS;
+                rw[i] = wsrc[g < NW ? g : NW - 1];
+            }
         }
     };
 
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                             if (a.drop_p > 0.f) {
                                 float sc[4];
                                 const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
-                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
+                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0) + a.hash_base, dp, sc);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
                             }
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
                             }
                             if (a.drop_p > 0.f) {
                                 float sc[4];
-                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0), dp, sc);
+                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0) + a.hash_base, dp, sc);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
                             }
@@ -1053,7 +1067,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     }
 }
 
-template <int BM, int NT, bool LK = false>
+template <int BM, int NT, bool LK = false, bool SUBW = false>
 int launch_conv_deep(const ConvArgs &a, hipStream_t st)
 {
     using C = DeepCfg<BM, NT>;
@@ -1062,7 +1076,7 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
         if (C::SMEM > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT, LK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT, LK, SUBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)C::SMEM));
         attr_set[dev & 63] = true;
     }
@@ -1072,12 +1086,71 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     const int per_xcd = (total + 7) / 8;
     int nb = 32 / groups;                                    // one 8-wave block per CU, 32 CUs per XCD
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
+    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK, SUBW>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
 
+// Rounds of tiles the persistent grid of the plain launch walks (one 8-wave block per CU): blocks of an XCD share its
+// contiguous range of tiles.
+int deep_rounds(int B, int H, int W, int cout, int BM, int NT, int *tiles_per_image)
+{
+    const int TH = BM >= 128 ? 4 : 8;
+    const int tpi = ((W + NT * 16 - 1) / (NT * 16)) * ((H + TH - 1) / TH);
+    const int groups = (cout + BM - 1) / BM;
+    const int nb = std::max(1, 32 / groups), per_xcd = (B * tpi + 7) / 8;
+    if (tiles_per_image) *tiles_per_image = tpi;
+    return (per_xcd + nb - 1) / nb;
+}
+
+int dispatch_conv_deep_plain(const ConvArgs &a, hipStream_t st);
+
+// Tile quantisation (round 4).  At the 80 x 80 and 40 x 40 levels a launch is a few hundred tiles on 256 CUs: 320 tiles are two
+// rounds of which the second keeps 64 CUs busy (dec0.x, dec1.x forward, four data gradients: 62 % of the chip over the launch).
+// Such a launch is split by images: the first images fill exactly one round with the layer's own kernel, the rest run as a
+// second launch of 32-channel blocks (4 x / 2 x the blocks for a quarter / half of the work each), which fits one round of its
+// own.  Same arithmetic per output element (the k order does not depend on the block width) and the same dropout draws (the
+// element index continues across the split: ConvArgs::hash_base): results are bit-identical to the single launch.
 int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
+{
+    const int BM = conv_cm(a.CIN, a.COUT);
+    const bool narrow = a.W <= 48;
+    const int NT = narrow ? 3 : 5;
+    const char *split_env = getenv("MMK_CONV_SPLIT");       // MMK_CONV_SPLIT=0: always one launch (A/B, bit-identity test; read per call)
+    const bool split_on = !(split_env && split_env[0] == '0');
+    int tpi = 0;
+    if (split_on && a.slope == 0.f && (BM == 64 || BM == 128) && a.COUT % 32 == 0 && a.pool_y == nullptr && a.wpack_mtb == 0 &&
+        deep_rounds(a.B, a.H, a.W, a.COUT, BM, NT, &tpi) == 2) {
+        const int groups = (a.COUT + BM - 1) / BM, nb = std::max(1, 32 / groups);
+        const int Bm = (8 * nb) / tpi;                      // images that fill one round
+        const int Bt = a.B - Bm;
+        const bool under_filled = (long)a.B * tpi * groups * 10 < (long)256 * 2 * 7;          // < 70 % of two rounds
+        if (Bm >= 1 && Bt >= 1 && under_filled && deep_rounds(Bm, a.H, a.W, a.COUT, BM, NT, nullptr) == 1 &&
+            deep_rounds(Bt, a.H, a.W, a.COUT, 32, NT, nullptr) == 1 && (a.o1.C % 32 == 0) && (a.o2.C % 32 == 0)) {
+            ConvArgs m = a;
+            m.B = Bm;
+            int rc = dispatch_conv_deep_plain(m, st);
+            if (rc != MMK_OK) return rc;
+            ConvArgs t = a;
+            const size_t px = (size_t)Bm * a.H * a.W;
+            t.B = Bt;
+            t.x1 = a.x1 + px * a.C1;
+            if (a.x2) t.x2 = a.x2 + px * a.C2;
+            auto adv = [&](ConvOutPart &o) {
+                if (o.y) o.y += px * o.C;
+                if (o.relu_src) o.relu_src += px * o.C;
+            };
+            adv(t.o1);
+            adv(t.o2);
+            t.hash_base = a.hash_base + (unsigned)(px * a.COUT);
+            t.wpack_mtb = BM / 16;
+            return narrow ? launch_conv_deep<32, 3, false, true>(t, st) : launch_conv_deep<32, 5, false, true>(t, st);
+        }
+    }
+    return dispatch_conv_deep_plain(a, st);
+}
+
+int dispatch_conv_deep_plain(const ConvArgs &a, hipStream_t st)
 {
     const int BM = conv_cm(a.CIN, a.COUT);
     const bool narrow = a.W <= 48;          // NT = 3 (48-pixel tile rows) wastes less than NT = 5 there

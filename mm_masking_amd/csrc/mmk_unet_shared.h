@@ -32,6 +32,11 @@ struct ConvArgs {
     float drop_p;          // forward dropout on the output (0 = none)
     unsigned seed;
     bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
+    // sub-batch launches of dispatch_conv_deep (round 4): the element index of the dropout draws continues where the images in
+    // front of this sub-batch end, and the packed weights may be laid out for a wider block than the kernel's own (wpack_mtb =
+    // 16-channel tiles per group of the packing, 0 = the kernel's own width)
+    unsigned hash_base = 0;
+    int wpack_mtb = 0;
 };
 
 // Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index e4 (a multiple of 4): four

@@ -1,6 +1,6 @@
-"""A/B of the LDS-DMA deep convolution (mmk_conv_dx.hip, default) against conv3x3_deep_kernel (MMK_CONV_DX=0) in ONE process:
-bit-identity of the outputs and interleaved timings for every >= 64-channel forward / data-gradient launch shape of the
-network at the bench size.  Development tool (run on the GPU box):  python scripts/ab_dx.py [B] [rounds]"""
+"""A/B of one library switch in ONE process: every >= 64-channel forward / data-gradient launch shape of the network at the bench
+size is run with the environment variable VAR = "0" (column "deep") and VAR = "1" (column "dx"), interleaved; bit-identity of the
+outputs and median timings.  Development tool (run on the GPU box):  python scripts/ab_env.py MMK_CONV_SPLIT [B] [rounds]"""
 import os
 import sys
 
@@ -10,8 +10,9 @@ sys.path.insert(0, ".")
 from mm_masking_amd import unet_hip as uh  # noqa: E402
 
 DEV = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+VAR = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 
 
 def rnd(*shape):
@@ -58,7 +59,7 @@ def main():
 
         res = {}
         for mode in ("0", "1"):
-            os.environ["MMK_CONV_DX"] = mode
+            os.environ[VAR] = mode
             y = torch.zeros(B, H, H, co, dtype=torch.bfloat16, device=DEV)
             fwd(y)
             if c2:
@@ -74,7 +75,7 @@ def main():
         td = {"0": [], "1": []}
         for _ in range(ROUNDS):
             for mode in ("0", "1"):
-                os.environ["MMK_CONV_DX"] = mode
+                os.environ[VAR] = mode
                 tf[mode].append(timeit(lambda: fwd(res[mode][0])))
                 td[mode].append(timeit(lambda: dgrad(res[mode][1])))
         f0, f1, d0, d1 = (sorted(v)[len(v) // 2] for v in (tf["0"], tf["1"], td["0"], td["1"]))
@@ -87,7 +88,7 @@ def main():
             a, b = res["0"][0].float(), res["1"][0].float()
             print("   fwd max |diff| %.4g, differing elements %d of %d" % ((a - b).abs().max().item(), int((a != b).sum()), a.numel()))
     print("sum us: fwd deep %.0f dx %.0f | dgrad deep %.0f dx %.0f" % (tot["f0"], tot["f1"], tot["d0"], tot["d1"]))
-    os.environ.pop("MMK_CONV_DX", None)
+    os.environ.pop(VAR, None)
 
 
 if __name__ == "__main__":
