@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 400 /* 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
+#define MMK_VERSION 401 /* 0.4.1: mmk_pose_loss_*, mmk_bce_mean_*; 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -143,6 +143,22 @@ int mmk_nn_search(const float *source /*B,N,3*/, const float *target_planar,
  * times whole epochs, train_icp_weights.py:518-523).                                    */
 int mmk_nn_profile_begin(int32_t capacity);
 int mmk_nn_profile_end(float *ms_out /*host*/, int32_t max_out, int32_t *n_out /*host*/);
+
+/* ------------------------------------------------------------------ loss terms of train_icp_weights.py:179-253
+ * One launch each (plus an ordered final sum) instead of ~45 PyTorch launches per step; deterministic (no float atomics).
+ * mmk_pose_loss_fwd: out2[0] = mean_b |T[b,1,0]|  (loss_rot, :199), out2[1] = mean_b ||(T[b,0,3], T[b,1,3])||  (loss_trans, :200)
+ *   of xi = T_pred - I (the gt_eye form, :193).  _bwd: grad_T (B,16) = g_rot * d rot / dT + g_trans * d trans / dT, with g_rot /
+ *   g_trans DEVICE scalars (NULL = 0): sign(.) / B and (x, y) / norm / B, zero where the norm is zero (as torch.norm's backward).
+ * mmk_bce_mean_fwd: out[0] = torch.nn.BCELoss()(x, target) over n elements (logs clamped at -100), ws = mmk_bce_ws_bytes()
+ *   bytes of device workspace.  _bwd: grad_x = grad_out[0] * (x - t) / max((1 - x) x, 1e-12) / n, grad_out a device scalar.    */
+int mmk_pose_loss_fwd(const float *T_pred /*B,16*/, int32_t B, float *out2, void *stream);
+int mmk_pose_loss_bwd(const float *T_pred, int32_t B, const float *g_rot, const float *g_trans,
+                      float *grad_T /*B,16*/, void *stream);
+size_t mmk_bce_ws_bytes(void);
+int mmk_bce_mean_fwd(const float *x, const float *target, int64_t n, void *ws, size_t ws_bytes,
+                     float *out, void *stream);
+int mmk_bce_mean_bwd(const float *x, const float *target, int64_t n, const float *grad_out,
+                     float *grad_x, void *stream);
 
 /* ------------------------------------------------------------------ radar_utils.py
  * mmk_cfar_mask        <- cfar_mask                      radar_utils.py:29-69

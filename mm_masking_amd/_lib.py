@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SO_PATH = os.environ.get("MMK_LIB", os.path.join(_HERE, "libmmk_hip.so"))   # MMK_LIB: A/B another build (development)
-SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip", "mmk_unet_driver.hip", "mmk_loader.hip"]
+SOURCES = ["mmk_api.hip", "mmk_icp.hip", "mmk_radar.hip", "mmk_unet.hip", "mmk_unet_driver.hip", "mmk_loader.hip", "mmk_loss.hip"]
 
 _lib = None
 
@@ -116,6 +116,11 @@ def _declare(lib):
         "mmk_icp_forward": (ctypes.c_int, [P] + [c_vp] * 10 + [c_vp, sz, ctypes.POINTER(ctypes.c_int), c_vp]),
         "mmk_icp_backward": (ctypes.c_int, [P] + [c_vp] * 11 + [c_vp, sz, c_vp]),
         "mmk_icp_status": (ctypes.c_int, [P, c_vp, sz, c_vp, c_vp]),
+        "mmk_pose_loss_fwd": (ctypes.c_int, [c_vp, i32, c_vp, c_vp]),
+        "mmk_pose_loss_bwd": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, c_vp, c_vp]),
+        "mmk_bce_ws_bytes": (sz, []),
+        "mmk_bce_mean_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, sz, c_vp, c_vp]),
+        "mmk_bce_mean_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp]),
         "mmk_icp_partials_count": (sz, [P]),
         "mmk_icp_accumulate": (ctypes.c_int, [P] + [c_vp] * 8 + [c_vp]),
         "mmk_icp_solve_update": (ctypes.c_int, [P] + [c_vp] * 7 + [c_vp]),

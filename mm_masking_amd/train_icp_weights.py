@@ -83,18 +83,87 @@ def _const(kind, device, dtype):
     return t
 
 
+# ----------------------------------------------------------------------------- loss terms as single launches (HIP tensors)
+_BCE_WS = {}
+
+
+class _PoseLossFn(torch.autograd.Function):
+    """(loss_rot, loss_trans) of the gt_eye form (train_icp_weights.py:193,197-200) in one launch, their gradient in another
+    (csrc/mmk_loss.hip) -- through PyTorch the two terms and their backward were ~25 launches of 2-5 us."""
+
+    @staticmethod
+    def forward(ctx, T_pred):
+        from . import _lib
+        T = T_pred.contiguous().float()
+        out = torch.empty(2, dtype=torch.float32, device=T.device)
+        _lib.check(_lib.lib().mmk_pose_loss_fwd(_lib.ptr(T), T.shape[0], _lib.ptr(out), _lib.stream_ptr(T.device)))
+        ctx.save_for_backward(T)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_rot, g_trans):
+        from . import _lib
+        (T,) = ctx.saved_tensors
+        gT = torch.empty_like(T)
+        gr = None if g_rot is None else g_rot.contiguous().float()
+        gt = None if g_trans is None else g_trans.contiguous().float()
+        _lib.check(_lib.lib().mmk_pose_loss_bwd(_lib.ptr(T), T.shape[0], _lib.ptr(gr), _lib.ptr(gt), _lib.ptr(gT), _lib.stream_ptr(T.device)))
+        return gT
+
+
+class _BceMeanFn(torch.autograd.Function):
+    """torch.nn.BCELoss()(mask, target) (mean reduction, logs clamped at -100) as one pass + an ordered final sum, and its
+    gradient as one pass (csrc/mmk_loss.hip); deterministic.  (An input outside [0, 1] gives NaN here where torch raises.)"""
+
+    @staticmethod
+    def forward(ctx, mask, target):
+        from . import _lib
+        L = _lib.lib()
+        x, t = mask.contiguous().float(), target.contiguous().float()
+        if x.shape != t.shape:
+            raise ValueError("Using a target size (%s) that is different to the input size (%s) is deprecated. "
+                             "Please ensure they have the same size." % (tuple(t.shape), tuple(x.shape)))
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _BCE_WS.get(key)
+        if ws is None:
+            ws = _BCE_WS[key] = torch.empty(int(L.mmk_bce_ws_bytes()), dtype=torch.uint8, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.check(L.mmk_bce_mean_fwd(_lib.ptr(x), _lib.ptr(t), x.numel(), _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(x, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, t = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().mmk_bce_mean_bwd(_lib.ptr(x), _lib.ptr(t), x.numel(), _lib.ptr(g.contiguous().float()), _lib.ptr(gx),
+                                               _lib.stream_ptr(x.device)))
+        return gx, None
+
+
+def _bce_mean(mask, target):
+    """mask_criterion(mask, target) of the reference (torch.nn.BCELoss, train_icp_weights.py:180): the fused kernels on a HIP
+    device, PyTorch's own on the CPU (host-logic tests)."""
+    if mask.is_cuda and mask.dtype == torch.float32:
+        return _BceMeanFn.apply(mask, target)
+    return torch.nn.BCELoss()(mask, target)
+
+
 def eval_training_loss(T_pred, mask, num_non0, batch_T_gt, batch_scan, batch_map, model, loss_weights=[],
                        icp_loss_only_iter=0, gt_eye=True, epoch=0):
     """train_icp_weights.py:179-253.  Same values and shapes as the reference's expression
     ``w_rot * loss_rot + ... + w_num * loss_num_pts`` (a term that is switched off is a (1,) zero there, so the sum has
     shape (1,) whenever one is); the switched-off terms are not multiplied and added on the GPU, though: they are a
     shared constant zero (x + 0 = x bit for bit), which takes ~20 two-microsecond launches out of a training step."""
-    mask_criterion = torch.nn.BCELoss()
+    mask_criterion = _bce_mean
     dev, dt = T_pred.device, T_pred.dtype
     zero = _const("zero", dev, dt)
     terms = {"rot": None, "trans": None, "fft": None, "mask_pts": None, "cfar": None, "num_pts": None}
 
-    if loss_weights["icp_rot"] > 0.0 or loss_weights["icp_trans"] > 0.0:
+    if (loss_weights["icp_rot"] > 0.0 or loss_weights["icp_trans"] > 0.0) and gt_eye and T_pred.is_cuda and dt == torch.float32:
+        terms["rot"], terms["trans"] = _PoseLossFn.apply(T_pred)          # one launch each way (csrc/mmk_loss.hip)
+    elif loss_weights["icp_rot"] > 0.0 or loss_weights["icp_trans"] > 0.0:
         eye = _const("eye", dev, dt)
         if gt_eye:
             xi_wedge = T_pred - eye
