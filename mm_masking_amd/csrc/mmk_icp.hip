@@ -438,11 +438,11 @@ __global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
     constexpr int NCH = TT / 32;                     // chunks per sub-tile (one flag bit each)
     constexpr int TPT = TT / NN_THREADS;             // targets a thread stages: 4 (dim 2) or 2 (dim 3)
     __shared__ __attribute__((aligned(16))) uint4 frag[KS][NCH][64];             // 32 KB: A fragments of the sub-tile
-    // the fp32 planes (exact re-scan), 8 / 6 KB.  In the re-scan every lane reads the eight float4s of ITS OWN flagged chunk; laid
-    // out plainly, all chunks of one parity share eight 16-byte bank slots (up to 8-way conflicts among the 16 lanes the LDS
-    // serves together: 45 % of the kernel's LDS cycles were conflict cycles, profiles/r03_nn_pmc_counters.json).  So float4 h
-    // of chunk c sits at position h ^ ((c >> 1) & 7) of the chunk: 16 consecutive chunks then cover all sixteen slots at every
-    // h (no padding: the block's 40 KB are what lets four blocks share a CU).
+    // the fp32 planes (exact re-scan), 8 / 6 KB, laid out plainly.  In the re-scan every lane reads the eight float4s of ITS OWN
+    // flagged chunk, so chunks of one parity share eight 16-byte bank slots and 45 % of the kernel's LDS cycles are conflict
+    // cycles (profiles/r03_nn_pmc_counters.json) -- which costs no time: a conflict-free image (float4 h of chunk c at position
+    // h ^ ((c >> 1) & 7)) was measured 1-3 us per launch SLOWER (131-134 against 130-131 us: eight more vector instructions
+    // per re-scanned chunk on a loop the vector pipe binds, round 4), so the plain image stays.
     __shared__ __attribute__((aligned(16))) float lt[DIM][TT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
             {   // stage: this thread's TPT targets -> the fp32 planes and rows TPT (tid % (32 / TPT)) .. of fragment tid / (32 / TPT)
                 float xs[TPT], ys[TPT], zs[TPT];
                 const int ch = tid / (32 / TPT), p4 = (tid % (32 / TPT)) * TPT;      // chunk, first target inside the chunk
-                const int lpos = ch * 32 + ((((p4 >> 2) ^ ((ch >> 1) & 7)) << 2) | (p4 & 3));
+                const int lpos = ch * 32 + p4;
                 if constexpr (TPT == 4) {
                     const float4 vx = *reinterpret_cast<const float4 *>(tb + (size_t)t * TT + tid * 4);
                     const float4 vy = *reinterpret_cast<const float4 *>(tb + (size_t)Mpad + (size_t)t * TT + tid * 4);
@@ -700,15 +700,15 @@ __global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
                     pq[0] = second ? pox[1] : pox[0];
                     pq[1] = second ? poy[1] : poy[0];
                     if constexpr (DIM == 3) pq[DIM - 1] = second ? poz[1] : poz[0];
-                    const int o0 = c * 32, sw = ((c >> 1) & 7) * 4;
+                    const int o0 = c * 32;
                     float best = INFINITY;
                     int bj = 0;
 #pragma unroll
                     for (int h = 0; h < 8; ++h) {
-                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + ((h * 4) ^ sw)]);
-                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + ((h * 4) ^ sw)]);
+                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
+                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
                         float4 vz = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if constexpr (DIM == 3) vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][o0 + ((h * 4) ^ sw)]);
+                        if constexpr (DIM == 3) vz = *reinterpret_cast<const float4 *>(&lt[DIM - 1][o0 + h * 4]);
                         const float d0 = nn_dist<DIM>(vx.x, vy.x, vz.x, pq), d1 = nn_dist<DIM>(vx.y, vy.y, vz.y, pq);
                         const float d2 = nn_dist<DIM>(vx.z, vy.z, vz.z, pq), d3 = nn_dist<DIM>(vx.w, vy.w, vz.w, pq);
                         if (d0 < best) { best = d0; bj = h * 4 + 0; }

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__
     float *row = reinterpret_cast<float *>(cs + (R + 1));          // R
     __shared__ double wsum[RT / 64];
     const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * R;
+    // (16-byte loads / stores were tried in round 4: no change, 107 -> 112 us -- the kernel is bound by the latency of one row per
+    // block at four blocks per CU (40 KB of LDS each), not by the width of its accesses)
     for (int c = threadIdx.x; c < R; c += RT) row[c] = raw[base + c];
     __syncthreads();
     const int L = (R + RT - 1) / RT;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__
     }
     if (threadIdx.x == RT - 1) cs[R] = tot;
     __syncthreads();
-    for (int c = threadIdx.x; c < R; c += RT) {
+    auto cell = [&](int c) -> float {
         float th = 1000.0f;
         if (c >= mincol && c < maxcol) {
             const float left = (float)(cs[c - guard] - cs[c - w2 - guard]);
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__
         } else {
             m = (x > th) ? 1.0f : 0.0f;
         }
-        mask[base + c] = m;
-    }
+        return m;
+    };
+    for (int c = threadIdx.x; c < R; c += RT) mask[base + c] = cell(c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -123,12 +126,26 @@ __device__ __forceinline__ float peak_value(const float *__restrict__ mrow, int 
     return a0 * z1 + a1 * z0;
 }
 
+// (both row kernels stage the mask row in LDS with 16-byte loads -- every cell is needed twice, as mrow[j] and mrow[j + 1] --
+// instead of two dword loads per cell)
+__device__ __forceinline__ const float *stage_row(const float *__restrict__ grow, int R, float *lrow)
+{
+    if ((R & 3) == 0 && ((uintptr_t)grow & 15) == 0) {
+        for (int c = threadIdx.x * 4; c < R; c += RT * 4) *reinterpret_cast<float4 *>(lrow + c) = *reinterpret_cast<const float4 *>(grow + c);
+    } else {
+        for (int c = threadIdx.x; c < R; c += RT) lrow[c] = grow[c];
+    }
+    __syncthreads();
+    return lrow;
+}
+
 __global__ __launch_bounds__(RT) void peaks_count_kernel(const float *__restrict__ mask, int R, float res, int diff,
                                                          float steep, int32_t *__restrict__ row_count)
 {
+    extern __shared__ __attribute__((aligned(16))) float lrow_dyn[];
     __shared__ int sm[RT / 64];
     const int rowid = blockIdx.y * gridDim.x + blockIdx.x;
-    const float *mrow = mask + (size_t)rowid * R;
+    const float *mrow = stage_row(mask + (size_t)rowid * R, R, lrow_dyn);
     int cnt = 0;
     for (int j = threadIdx.x; j < R - 1; j += RT) cnt += (peak_value(mrow, j, R, res, diff, steep) != 0.0f) ? 1 : 0;
     int tot;
@@ -158,10 +175,11 @@ __global__ __launch_bounds__(RT) void peaks_emit_kernel(const float *__restrict_
                                                         float steep, const int32_t *__restrict__ row_off, int cap,
                                                         float *__restrict__ mval, int32_t *__restrict__ mrow_out)
 {
+    extern __shared__ __attribute__((aligned(16))) float lrow_dyn[];
     __shared__ int sm[RT / 64];
     const int a = blockIdx.x, b = blockIdx.y, A = gridDim.x;
     const int rowid = b * A + a;
-    const float *mrow = mask + (size_t)rowid * R;
+    const float *mrow = stage_row(mask + (size_t)rowid * R, R, lrow_dyn);
     int base = row_off[rowid];
     for (int j0 = 0; j0 < R - 1; j0 += RT) {
         const int j = j0 + threadIdx.x;
@@ -608,11 +626,13 @@ extern "C" int mmk_extract_peaks(const float *mask, int32_t B, int32_t A, int32_
         return MMK_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(peaks_count_kernel, dim3(A, B), dim3(RT), 0, st, mask, R, res, diff, steep_fact, w.row_count);
+    const size_t row_lds = (size_t)R * sizeof(float);
+    MMK_REQUIRE(row_lds <= 64 * 1024 - 64, "mmk_extract_peaks: R=%d does not fit the LDS row buffer", R);
+    hipLaunchKernelGGL(peaks_count_kernel, dim3(A, B), dim3(RT), row_lds, st, mask, R, res, diff, steep_fact, w.row_count);
     MMK_LAUNCH_CHECK();
     hipLaunchKernelGGL(peaks_scan_kernel, dim3(B), dim3(RT), 0, st, w.row_count, A, w.row_off, w.total);
     MMK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(peaks_emit_kernel, dim3(A, B), dim3(RT), 0, st, mask, R, res, diff, steep_fact, w.row_off, w.cap,
+    hipLaunchKernelGGL(peaks_emit_kernel, dim3(A, B), dim3(RT), row_lds, st, mask, R, res, diff, steep_fact, w.row_off, w.cap,
                        w.mval, w.mrow);
     MMK_LAUNCH_CHECK();
     hipLaunchKernelGGL(peaks_pair_kernel, dim3((max_pts + 255) / 256, B), dim3(256), 0, st, w.mval, w.mrow, w.cap,

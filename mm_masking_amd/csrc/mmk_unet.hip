@@ -1110,7 +1110,8 @@ int dispatch_conv_deep_plain(const ConvArgs &a, hipStream_t st);
 // Such a launch is split by images: the first images fill exactly one round with the layer's own kernel, the rest run as a
 // second launch of 32-channel blocks (4 x / 2 x the blocks for a quarter / half of the work each), which fits one round of its
 // own.  Same arithmetic per output element (the k order does not depend on the block width) and the same dropout draws (the
-// element index continues across the split: ConvArgs::hash_base): results are bit-identical to the single launch.
+// element index continues across the split: ConvArgs::hash_base): results are bit-identical to the single launch.  Measured in
+// one process (scripts/ab_env.py MMK_CONV_SPLIT): dec0.0 54 -> 48 us, dec0.2 32 -> 30, dec1.0 50 -> 47, dec1.2 33 -> 31.
 int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
 {
     const int BM = conv_cm(a.CIN, a.COUT);
@@ -1119,7 +1120,10 @@ int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
     const char *split_env = getenv("MMK_CONV_SPLIT");       // MMK_CONV_SPLIT=0: always one launch (A/B, bit-identity test; read per call)
     const bool split_on = !(split_env && split_env[0] == '0');
     int tpi = 0;
-    if (split_on && a.slope == 0.f && (BM == 64 || BM == 128) && a.COUT % 32 == 0 && a.pool_y == nullptr && a.wpack_mtb == 0 &&
+    // (forward launches only: in the backward pass the idle CUs of a data-gradient launch's second round are not idle -- the
+    // weight-gradient kernels of the side stream run there -- and the split cost the pass 0.15 ms instead of saving 0.01)
+    const bool forward_role = a.relu != 0 && a.o1.relu_src == nullptr && a.o2.relu_src == nullptr && !a.o1.accumulate && !a.o2.accumulate;
+    if (split_on && forward_role && a.slope == 0.f && (BM == 64 || BM == 128) && a.COUT % 32 == 0 && a.pool_y == nullptr && a.wpack_mtb == 0 &&
         deep_rounds(a.B, a.H, a.W, a.COUT, BM, NT, &tpi) == 2) {
         const int groups = (a.COUT + BM - 1) / BM, nb = std::max(1, 32 / groups);
         const int Bm = (8 * nb) / tpi;                      // images that fill one round

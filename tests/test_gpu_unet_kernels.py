@@ -756,8 +756,9 @@ def test_bwd16x8_fused_plain_bit_identical(B, H, W):
 def test_conv_deep_sub_batch_split_bit_identical(H, cin1, cin2, cout):
     """Round 4: a >= 64-channel launch whose tiles fill 1.25 rounds of the chip (B = 32 at the 80 x 80 / 40 x 40 levels) runs as
     two launches -- the first images with the layer's own kernel, the rest with 32-channel blocks on weights packed for the
-    wider block.  Forward (bias, ReLU, dropout: same draws across the split) and data gradient (two outputs, ReLU source)
-    are bit-identical to the single launch (MMK_CONV_SPLIT=0)."""
+    wider block.  The forward role (bias, ReLU, dropout: same draws across the split) is bit-identical to the single launch
+    (MMK_CONV_SPLIT=0); data-gradient launches are never split (they share the chip with the weight gradients' stream) and
+    are compared as well."""
     import os
     B, cin = 32, cin1 + cin2
     g = torch.Generator(device="cpu").manual_seed(H + cin + cout)
