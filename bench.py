@@ -290,8 +290,8 @@ def side_blocks(model, opt, lw, params, device, B, steps=5):
     finally:
         model.icp_dim = dim_was
     out["dim3"] = {"ms_per_step": ms3, "pairs_per_s": B / ms3 * 1e3,
-                   "note": "same step with icp_dim=3: SE(3) pose, 6x6 Gauss-Newton, 3-D nearest neighbour on a map with heights and "
-                           "tilted normals (synthetic.make_pair(dim=3))"}
+                   "note": "same step with icp_dim=3: SE(3) pose, 6x6 Gauss-Newton, 3-D nearest neighbour (nn_mfma_kernel<3>: two chained "
+                           "MFMAs per 32 x 32 pairs) on a map with heights and tilted normals (synthetic.make_pair(dim=3))"}
     del raws3
     model.eval()
     try:
@@ -546,11 +546,11 @@ def main():
             scanned = float((N_PAD - 512 * skipped.sum(dim=1)).float().mean().item())
         evals = active_pairs * scanned * M_PAD       # distance evaluations per launch
         # HBM bytes per launch from the PMC counters: NOT measured in this run -- read from a committed file that a separate
-        # rocprofv3 --pmc pass over the dICP alone wrote (scripts/pmc_nn.sh -> profiles/r03_nn_traffic.json, FETCH_SIZE and
+        # rocprofv3 --pmc pass over the dICP alone wrote (scripts/pmc_nn.sh -> profiles/r04_nn_traffic.json, FETCH_SIZE and
         # WRITE_SIZE in passes of their own, FETCH_SIZE doubled per the gfx950 correction); null when no such file exists.
         # `traffic_source` says so in the line itself.
         traffic, traffic_source = None, None
-        for name in ("r03_nn_traffic.json", "r02_nn_traffic.json"):
+        for name in ("r04_nn_traffic.json", "r03_nn_traffic.json", "r02_nn_traffic.json"):
             tr_file = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tr_file) and model.ICP_alg.nn_search == "brute":
                 tj = json.load(open(tr_file))
@@ -576,7 +576,7 @@ def main():
                        "equivalent_dense_bf16_tflops": evals / nn_avg_s * 32 / 1e12,
                        "note": "16 k-slots (2 x 16 flop) per pair: exact three-way bf16 splits of -2p, t and |t|^2, fp32 accumulation; "
                                "the fp32 VALU kernel of rounds 1-2 (MMK_NN_MFMA=0) issues 3.3 vector instructions per 64 pairs, this "
-                               "one 1.4 (profiles/r03_nn_pmc_counters.json)"}
+                               "one 1.4 (profiles/r04_nn_pmc_counters.json)"}
         else:
             binding = {"pipe": "fp32 VALU", "pair_evals_per_s": evals / nn_avg_s, "achieved_tflops": evals * 6 / nn_avg_s / 1e12,
                        "peak_tflops": VALU_PEAK_TFLOPS, "frac": evals * 6 / nn_avg_s / 1e12 / VALU_PEAK_TFLOPS, "flop_per_eval": 6,

@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 from mm_masking_amd import ddp, synthetic, train_icp_weights as trn
 from mm_masking_amd.dICP.ICP import ICP
 B = 32
+DIM = int(sys.argv[1]) if len(sys.argv) > 1 else 2      # 3: SE(3) scenes (synthetic.make_pair(dim=3)), nn_mfma_kernel<3>
 dev = torch.device("cuda:0")
 params = trn.default_params(dev)
 sets = {"0..31": list(range(32)), "32..63": list(range(32, 64)), "4000..": list(range(4000, 4032))}
@@ -21,7 +22,7 @@ for r in (0, 3, 7):
 icp = ICP("pt2pl", differentiable=True, max_iterations=10, tolerance=1e-5)
 tot_diff = 0
 for name, ids in sets.items():
-    raw = synthetic.make_batch(ids, device=dev)
+    raw = synthetic.make_batch(ids, device=dev, dim=DIM)
     batch = trn.prepare_batch(raw, params, max_loc_pts=5120)
     src = batch["loc_data"]["filtered_pc"]
     torch.manual_seed(5)
@@ -29,7 +30,7 @@ for name, ids in sets.items():
     outs = []
     for rep in range(2):
         w = w0.clone().requires_grad_(True)
-        T = icp.icp(src, raw["map_pc"], T_init=raw["T_init"], weight=w, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)["T"]
+        T = icp.icp(src, raw["map_pc"], T_init=raw["T_init"], weight=w, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=DIM)["T"]
         sv = T.grad_fn.saved_tensors
         idx, act = sv[3].cpu().numpy(), sv[7].cpu().numpy()[:-1]
         idx = np.where(act[:, :, None] != 0, idx, -7)

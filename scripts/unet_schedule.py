@@ -30,8 +30,36 @@ def schedule(B=32, H=640, W=640, cin0=1):
     def add(kernel, layer, role, rd, wr, flop=0.0):
         out.append({"kernel": kernel, "layer": layer, "role": role, "read_bytes": int(rd), "write_bytes": int(wr), "flop": float(flop)})
 
+    def split_images(lvl, cin, cout):
+        """dispatch_conv_deep's sub-batch split (csrc/mmk_unet.hip, round 4): forward launches of >= 64-channel layers whose
+        tiles fill 1.25 rounds of the chip run as two launches; -> images of the first launch (0: one launch)."""
+        if not is_deep(cin, cout) or cout % 64 != 0:
+            return 0
+        BM = 128 if cout >= 128 else 64
+        NT = 3 if rw[lvl] <= 48 else 5
+        TH = 4 if BM >= 128 else 8
+
+        def rounds(b, bm, th):
+            tpi = -(-rw[lvl] // (NT * 16)) * -(-rh[lvl] // th)
+            groups = -(-cout // bm)
+            nb = max(1, 32 // groups)
+            return -(-(-(-b * tpi // 8)) // nb), tpi, groups, nb
+        r, tpi, groups, nb = rounds(B, BM, TH)
+        if r != 2 or B * tpi * groups * 10 >= 256 * 2 * 7:
+            return 0
+        bm = (8 * nb) // tpi
+        if bm < 1 or bm >= B or rounds(bm, BM, TH)[0] != 1 or rounds(B - bm, 32, 8)[0] != 1:
+            return 0
+        return bm
+
     def conv(layer, role, lvl, cin, cout, extra_rd=0, extra_wr=0):
         n = px(lvl)
+        bm = split_images(lvl, cin, cout) if role.startswith("fwd") else 0
+        if bm:
+            for part, frac in (("first %d images" % bm, bm / B), ("last %d images, 32-channel blocks" % (B - bm), (B - bm) / B)):
+                add(conv_kernel(cin, cout), layer + " [" + part + "]", role, (n * cin * 2 + extra_rd) * frac, (n * cout * 2 + extra_wr) * frac,
+                    2.0 * 9 * cin * cout * n * frac)
+            return
         add(conv_kernel(cin, cout), layer, role, n * cin * 2 + extra_rd, n * cout * 2 + extra_wr, 2.0 * 9 * cin * cout * n)
 
     # ---------------- forward
@@ -81,22 +109,22 @@ def schedule(B=32, H=640, W=640, cin0=1):
         fuse = cs in (8, 16)
         # second application of the block's second conv
         if fuse:
-            fused("conv_bwd_fused_kernel<%d, %d>" % (cs, cs), "dec%d.2 (2nd application)" % j, lvl, cs, cs, cs)
+            fused("conv_bwd_fused_kernel<%d, %d," % (cs, cs), "dec%d.2 (2nd application)" % j, lvl, cs, cs, cs)
         else:
             wgrad("dec%d.2 (2nd application)" % j, lvl, cs, cs, cs)
             dgrad("dec%d.2 (2nd application)" % j, lvl, cs, cs, cs)
         if j == 4:
-            fused("conv_bwd_fused_kernel<16, 8>", "dec4.0 (2nd application)", lvl, 16, 8, 16)
+            fused("conv_bwd_fused_kernel<16, 8,", "dec4.0 (2nd application)", lvl, 16, 8, 16)
         else:
             wgrad("dec%d.0 (2nd application)" % j, lvl, 2 * cs, cs, cs)
             dgrad("dec%d.0 (2nd application)" % j, lvl, 2 * cs, cs, cs)          # (ReLU source: d1 half only)
         if fuse:
-            fused("conv_bwd_fused_kernel<%d, %d>" % (cs, cs), "dec%d.2 (1st application)" % j, lvl, cs, cs, cs)
+            fused("conv_bwd_fused_kernel<%d, %d," % (cs, cs), "dec%d.2 (1st application)" % j, lvl, cs, cs, cs)
         else:
             wgrad("dec%d.2 (1st application)" % j, lvl, cs, cs, cs)
             dgrad("dec%d.2 (1st application)" % j, lvl, cs, cs, cs)
         if j == 4:
-            fused("conv_bwd_fused_kernel<16, 8>", "dec4.0 (1st application)", lvl, 16, 8, 0)
+            fused("conv_bwd_fused_kernel<16, 8,", "dec4.0 (1st application)", lvl, 16, 8, 0)
         else:
             wgrad("dec%d.0 (1st application)" % j, lvl, 2 * cs, cs, 2 * cs)
             dgrad("dec%d.0 (1st application)" % j, lvl, 2 * cs, cs, 0)
@@ -104,20 +132,26 @@ def schedule(B=32, H=640, W=640, cin0=1):
     add("unpack_wgrad_batch_kernel", "dec", "reduce weight-gradient slices", 0, 0)
     for i in range(5, 0, -1):
         ch, lvl = ENC[i], i - 1
-        add("maxpool2_bwd_kernel", "enc%d.pool" % i, "bwd", px(lvl) * ch * 2 + px(i) * ch * 2, px(lvl) * ch * 2)
-        if ch in (8, 16):
-            fused("conv_bwd_fused_kernel<%d, %d>" % (ch, ch), "enc%d.2" % i, lvl, ch, ch, ch)
+        pool_fused = False      # (round 4 tried the pooling adjoint inside the fused launch: slower, scripts/experiments/r04_pool_fused_backward.patch)
+        if not pool_fused:
+            add("maxpool2_bwd_kernel", "enc%d.pool" % i, "bwd", px(lvl) * ch * 2 + px(i) * ch * 2, px(lvl) * ch * 2)
+        if pool_fused:
+            # reads x, the block's output d (for the routing) and the pooled gradient; writes dx
+            add("conv_bwd_fused_kernel<16, 16, true>", "enc%d.pool + enc%d.2" % (i, i), "pool bwd + dgrad+wgrad",
+                px(lvl) * (ch + ch) * 2 + px(i) * ch * 2, px(lvl) * ch * 2, 2.0 * 2 * 9 * ch * ch * px(lvl))
+        elif ch in (8, 16):
+            fused("conv_bwd_fused_kernel<%d, %d," % (ch, ch), "enc%d.2" % i, lvl, ch, ch, ch)
         else:
             wgrad("enc%d.2" % i, lvl, ch, ch, ch)
             dgrad("enc%d.2" % i, lvl, ch, ch, ch)
         if i == 1:
-            fused("conv_bwd_fused_kernel<8, 16>", "enc1.0", lvl, 8, 16, 8, extra_rd=px(lvl) * 8 * 2)       # (+ the skip gradient it adds to)
+            fused("conv_bwd_fused_kernel<8, 16,", "enc1.0", lvl, 8, 16, 8, extra_rd=px(lvl) * 8 * 2)       # (+ the skip gradient it adds to)
         else:
             wgrad("enc%d.0" % i, lvl, ENC[i - 1], ch, ENC[i - 1])
             dgrad("enc%d.0" % i, lvl, ENC[i - 1], ch, 0, acc_ch=ENC[i - 1])
         if i == 3:
             add("unpack_wgrad_batch_kernel", "enc3-5", "reduce weight-gradient slices", 0, 0)
-    fused("conv_bwd_fused_kernel<8, 8>", "enc0.2", 0, 8, 8, 8)
+    fused("conv_bwd_fused_kernel<8, 8,", "enc0.2", 0, 8, 8, 8)
     add("unpack_wgrad_batch_kernel", "enc0-2", "reduce weight-gradient slices", 0, 0)
     add("conv_first_wgrad_x4_kernel", "enc0.0", "wgrad", px(0) * (cin0 * 4 + 8 * 2), 0, 2.0 * 9 * cin0 * 8 * px(0))
     add("conv_first_wgrad_reduce_kernel", "enc0.0", "wgrad reduce", 0, 0)
