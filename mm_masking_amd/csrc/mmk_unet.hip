@@ -107,7 +107,17 @@ __device__ __forceinline__ void pack_conv_weight_elem(const float *__restrict__ 
         tap = 4 * s + (lane >> 4);
         ch = 0;
     }
-    const int co = group * CM + mt * 16 + (lane & 15);
+    // Row i of 16-channel tile mt = output channel co.  Thin layers: the 16 rows of a tile are 16 consecutive channels.  The
+    // >= 64-channel kernel (conv3x3_deep_kernel, round 4): a lane group g (16 lanes) ends up with rows 4g .. 4g + 3 of EVERY tile
+    // of its wave, so the rows are dealt such that those 4 x MTW values are 4 MTW CONSECUTIVE channels -- channel =
+    // (4 MTW) (i / 4) + 4 (tile within the wave) + i % 4 -- and the lane stores (and reads its epilogue operands as) one
+    // contiguous run per pixel, with no lane exchange in the epilogue.
+    int co = group * CM + mt * 16 + (lane & 15);
+    if (conv_is_deep(ci_n, co_n)) {
+        const int MTW = MT < 4 ? MT : 4;               // tiles per wave (DeepCfg::MT)
+        const int i = lane & 15;
+        co = group * CM + (mt / MTW) * (16 * MTW) + (4 * MTW) * (i >> 2) + 4 * (mt % MTW) + (i & 3);
+    }
     const int ci = chunk * CK + ch + j;
     float v = 0.f;
     if (tap < 9 && co < co_n && ci < ci_n) {
@@ -823,7 +833,11 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     // tile wait for those stores to drain: loads and stores share one counter and complete out of order with each other.
     float *bias_lds = reinterpret_cast<float *>(w_lds + (size_t)NW * 8);
     if (tid < BM) {
-        const int c = group * BM + tid;
+        int c = group * BM + tid;
+        if constexpr (SUBW) {      // the block's channels are a strided slice of the packed group: 4 MT per lane group (see the epilogue)
+            const int pm = a.wpack_mtb, per = pm / MTB, m_off = (group % per) * MTB;
+            c = (group / per) * (pm * 16) + (m_off / 4) * 64 + 16 * (tid / (4 * MT)) + 4 * (m_off % 4) + tid % (4 * MT);
+        }
         bias_lds[tid] = (a.bias && c < a.COUT) ? a.bias[c] : 0.f;
     }
     f32x4 acc[MT][NT];
@@ -892,171 +906,110 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
             const int b = tile / tpi, tr = tile - b * tpi;
             const int tyi = tr / tiles_x;
             const int tx0 = (tr - tyi * tiles_x) * C::TWD, yy = tyi * C::TH + wn;
-            // Wide path (the wave's four 16-channel tiles all exist): the MFMA layout gives lane group
-            // g = 2a+b (16 lanes each) 4 channels of each tile m = 2c+d, i.e. four 8-byte pieces 32 bytes
-            // apart.  One v_permlane16_swap per dword and tile pair (m = 2c, 2c+1) trades lane bit b for
-            // tile bit d; the lane then owns the two adjacent pieces 8c + 4b + 2a + {0,1} = 16 contiguous
-            // bytes at channel 32c + 16b + 8a, and one store instruction (fixed c) covers 64 contiguous
-            // bytes per pixel.  (8-byte pieces of 256-byte pixel rows cost 4x the algorithmic HBM write
-            // traffic: profiles/r01e_conv_traffic.json.)  Operands of the epilogue take the same route back.
-            // (the lane index behind an opaque asm: the per-lane output pointers are derived here, once per
-            // tile, instead of living in ~16 registers across the MFMA loop)
+            // The weights are packed so that the lane's 4 rows of each of its MT tiles are NCH = 4 MT consecutive output channels
+            // (pack_conv_weight_elem): tile m, register r = channel c0 + 4 m + r.  The lane therefore stores -- and reads its
+            // ReLU source / accumulate target as -- one contiguous run of 2 NCH bytes per pixel (two 16-byte pieces at 64 channels
+            // per wave), with no lane exchange: rounds 1-3 traded lane bits for tile bits with v_permlane16_swap here, which with
+            // its hazard padding and register copies was a third of the epilogue's ~1 500 instructions per tile (round 4: the
+            // epilogue alone is 16-24 us of a 60-GFLOP launch, profiles/r04_conv_dx_ablation_*.txt).
+            // (the lane index behind an opaque asm: the per-lane output pointers are derived here, once per tile,
+            // instead of living in registers across the MFMA loop)
             int lv = lane;
             asm volatile("" : "+v"(lv));
-            bool wide = false;
-            if constexpr (MT == 4) wide = (group * BM + (wm + 1) * 64 <= a.COUT);
-            if (wide) {
-                if constexpr (MT == 4) {
-                    const int g4 = lv >> 4;
-                    const int lane_ch = 16 * (g4 & 1) + 8 * (g4 >> 1);          // + 32 c
-                    bf16 *t_y[2];
-                    const bf16 *t_src[2];
-                    int t_C[2], t_cl[2];
-                    bool t_acc[2];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int ct = group * BM + wm * 64 + 32 * c + lane_ch;
-                        const bool fpt = ct < a.o1.C;
-                        t_y[c] = fpt ? a.o1.y : a.o2.y;
-                        t_src[c] = fpt ? a.o1.relu_src : a.o2.relu_src;
-                        t_C[c] = fpt ? a.o1.C : a.o2.C;
-                        t_acc[c] = (fpt ? a.o1.accumulate : a.o2.accumulate) != 0;
-                        t_cl[c] = fpt ? ct : ct - a.o1.C;
-                    }
-                    bool m_has_src[4];
-                    float m_scale[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
-                        const bool firstp = c0 < a.o1.C;
-                        m_has_src[m] = (firstp ? a.o1.relu_src : a.o2.relu_src) != nullptr;
-                        m_scale[m] = firstp ? a.o1.scale : a.o2.scale;
-                    }
-                    // x[m] <-> the piece layout (an involution)
-                    auto swap16 = [](unsigned (&x)[4]) {
-                        auto r01 = __builtin_amdgcn_permlane16_swap(x[0], x[1], false, false);
-                        auto r23 = __builtin_amdgcn_permlane16_swap(x[2], x[3], false, false);
-                        x[0] = r01[0]; x[1] = r01[1]; x[2] = r23[0]; x[3] = r23[1];
-                    };
-                    const bool any_src = a.o1.relu_src != nullptr || a.o2.relu_src != nullptr;
-                    const bool any_acc = a.o1.accumulate != 0 || a.o2.accumulate != 0;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int xx = tx0 + n * 16 + (lv & 15);
-                        const bool okp = yy < a.H && xx < a.W;
-                        const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                        unsigned slo[4] = {0, 0, 0, 0}, shi[4] = {0, 0, 0, 0}, alo[4] = {0, 0, 0, 0}, ahi[4] = {0, 0, 0, 0};
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            if (t_src[c] != nullptr && okp) {
-                                const u32x4 v = *reinterpret_cast<const u32x4 *>(t_src[c] + p * t_C[c] + t_cl[c]);
-                                slo[2 * c] = v[0]; shi[2 * c] = v[1]; slo[2 * c + 1] = v[2]; shi[2 * c + 1] = v[3];
-                            }
-                            if (t_acc[c] && okp) {
-                                const u32x4 v = *reinterpret_cast<const u32x4 *>(t_y[c] + p * t_C[c] + t_cl[c]);
-                                alo[2 * c] = v[0]; ahi[2 * c] = v[1]; alo[2 * c + 1] = v[2]; ahi[2 * c + 1] = v[3];
-                            }
-                        }
-                        if (any_src) { swap16(slo); swap16(shi); }     // back to the MFMA layout
-                        if (any_acc) { swap16(alo); swap16(ahi); }
-                        unsigned lo[4], hi[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            float v[4];
-                            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + (wm * 4 + m) * 16 + g4 * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[m][n][r] + bv[r];
-                                if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
-                            }
-                            if (a.drop_p > 0.f) {
-                                float sc[4];
-                                const int c0 = group * BM + (wm * 4 + m) * 16 + g4 * 4;
-                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0) + a.hash_base, dp, sc);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
-                            }
-                            if (m_has_src[m]) {
-                                const bf16x4 sv = __builtin_bit_cast(bf16x4, (unsigned long long)slo[m] | ((unsigned long long)shi[m] << 32));
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    v[r] = lk ? v[r] * bwd_factor_leaky((float)sv[r], m_scale[m], a.slope)
-                                              : (((float)sv[r] > 0.f) ? v[r] * m_scale[m] : 0.f);
-                            }
-                            if (any_acc) {
-                                const bf16x4 ov = __builtin_bit_cast(bf16x4, (unsigned long long)alo[m] | ((unsigned long long)ahi[m] << 32));
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];      // zeros where the part does not accumulate
-                            }
-                            bf16x4 outv;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
-                            const unsigned long long pk = __builtin_bit_cast(unsigned long long, outv);
-                            lo[m] = (unsigned)pk;
-                            hi[m] = (unsigned)(pk >> 32);
-                        }
-                        swap16(lo);
-                        swap16(hi);
-                        if (okp) {
-#pragma unroll
-                            for (int c = 0; c < 2; ++c) {
-                                const u32x4 w = {lo[2 * c], hi[2 * c], lo[2 * c + 1], hi[2 * c + 1]};
-                                *reinterpret_cast<u32x4 *>(t_y[c] + p * t_C[c] + t_cl[c]) = w;
-                            }
-                        }
-                    }
-                }
+            constexpr int NCH = 4 * MT;
+            const int g4 = lv >> 4;
+            int c0;                                          // first of the lane's NCH channels
+            int bias_at;                                     // ... and where their bias sits in bias_lds
+            if constexpr (SUBW) {
+                const int pm = a.wpack_mtb, per = pm / MTB, m_off = (group % per) * MTB;
+                c0 = (group / per) * (pm * 16) + (m_off / 4) * 64 + 16 * g4 + 4 * (m_off % 4);
+                bias_at = NCH * g4;
             } else {
+                c0 = group * BM + wm * (16 * MT) + NCH * g4;
+                bias_at = wm * (16 * MT) + NCH * g4;
+            }
+            if (c0 < a.COUT) {
+                const bool firstp = c0 < a.o1.C;
+                bf16 *const o_y = firstp ? a.o1.y : a.o2.y;
+                const bf16 *const o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
+                const int o_C = firstp ? a.o1.C : a.o2.C;
+                const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
+                const float o_scale = firstp ? a.o1.scale : a.o2.scale;
+                const int cl = firstp ? c0 : c0 - a.o1.C;
+                float bv[NCH];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int c0 = group * BM + (wm * MT + m) * 16 + (lv >> 4) * 4;
-                if (c0 < a.COUT) {
-                    const bool firstp = c0 < a.o1.C;
-                    bf16 *o_y = firstp ? a.o1.y : a.o2.y;
-                    const bf16 *o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
-                    const int o_C = firstp ? a.o1.C : a.o2.C;
-                    const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
-                    const float o_scale = firstp ? a.o1.scale : a.o2.scale;
-                    const int cl = firstp ? c0 : c0 - a.o1.C;
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + (wm * MT + m) * 16 + (lv >> 4) * 4);
+                for (int k = 0; k < NCH; k += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(bias_lds + bias_at + k);
+                    bv[k] = t[0]; bv[k + 1] = t[1]; bv[k + 2] = t[2]; bv[k + 3] = t[3];
+                }
+                const int x0 = tx0 + (lv & 15);
+                const long p0 = ((long)b * a.H + yy) * a.W + x0;                 // the lane's pixel of n-tile 0
+                const unsigned e0 = (unsigned)p0 * (unsigned)a.COUT + (unsigned)c0 + a.hash_base;       // dropout element index
+                const unsigned e_step = 16u * (unsigned)a.COUT;
+                bf16 *const y0 = o_y + p0 * o_C + cl;
+                const bf16 *const s0 = o_src ? o_src + p0 * o_C + cl : nullptr;
+                const int step = 16 * o_C;                                        // elements between the pixels of consecutive n-tiles
+                const bool row_ok = yy < a.H;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int xx = tx0 + n * 16 + (lv & 15);
-                        if (yy < a.H && xx < a.W) {
-                            const size_t p = ((size_t)b * a.H + yy) * a.W + xx;
-                            float v[4];
+                for (int n = 0; n < NT; ++n) {
+                    const bool okp = row_ok && x0 + n * 16 < a.W;
+                    float v[NCH];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[m][n][r] + bv[r];
-                                if (a.relu) v[r] = lk ? act_leaky(v[r], a.slope) : fmaxf(v[r], 0.f);
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = acc[m][n][r] + bv[4 * m + r];
+                            if (a.relu) t = lk ? act_leaky(t, a.slope) : fmaxf(t, 0.f);
+                            v[4 * m + r] = t;
+                        }
+                    if (a.drop_p > 0.f) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            float sc[4];
+                            dropout_scale4(a.seed, e0 + (unsigned)n * e_step + 4u * m, dp, sc);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[4 * m + r] = lk ? drop_leaky(v[4 * m + r], sc[r]) : v[4 * m + r] * sc[r];
+                        }
+                    }
+                    bf16 *const dst = y0 + n * step;
+                    constexpr int LW = NCH >= 8 ? 8 : 4;                 // channels per operand load (16 or 8 bytes)
+                    typedef __attribute__((ext_vector_type(LW))) __bf16 bfl;
+                    if (o_src && okp) {
+                        const bf16 *sp = s0 + n * step;
+#pragma unroll
+                        for (int k = 0; k < NCH; k += LW) {
+                            const bfl sv = *reinterpret_cast<const bfl *>(sp + k);
+#pragma unroll
+                            for (int r = 0; r < LW; ++r)
+                                v[k + r] = lk ? v[k + r] * bwd_factor_leaky((float)sv[r], o_scale, a.slope)
+                                              : (((float)sv[r] > 0.f) ? v[k + r] * o_scale : 0.f);
+                        }
+                    }
+                    if (o_acc && okp) {
+#pragma unroll
+                        for (int k = 0; k < NCH; k += LW) {
+                            const bfl ov = *reinterpret_cast<const bfl *>(dst + k);
+#pragma unroll
+                            for (int r = 0; r < LW; ++r) v[k + r] += (float)ov[r];
+                        }
+                    }
+                    if (okp) {
+                        if constexpr (NCH >= 8) {
+#pragma unroll
+                            for (int k = 0; k < NCH; k += 8) {
+                                bf16x8 o8;
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) o8[r] = (bf16)v[k + r];
+                                *reinterpret_cast<bf16x8 *>(dst + k) = o8;
                             }
-                            if (a.drop_p > 0.f) {
-                                float sc[4];
-                                dropout_scale4(a.seed, (unsigned)(p * a.COUT + c0) + a.hash_base, dp, sc);
+                        } else {
+                            bf16x4 o4;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = lk ? drop_leaky(v[r], sc[r]) : v[r] * sc[r];
-                            }
-                            bf16 *dst = o_y + p * o_C + cl;
-                            if (o_src) {
-                                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(o_src + p * o_C + cl);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    v[r] = lk ? v[r] * bwd_factor_leaky((float)sv[r], o_scale, a.slope)
-                                              : (((float)sv[r] > 0.f) ? v[r] * o_scale : 0.f);
-                            }
-                            if (o_acc) {
-                                const bf16x4 ov = *reinterpret_cast<const bf16x4 *>(dst);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
-                            }
-                            bf16x4 outv;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) outv[r] = (bf16)v[r];
-                            *reinterpret_cast<bf16x4 *>(dst) = outv;
+                            for (int r = 0; r < 4; ++r) o4[r] = (bf16)v[r];
+                            *reinterpret_cast<bf16x4 *>(dst) = o4;
                         }
                     }
                 }
-            }
             }
             reset_acc();
         }
