@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 401 /* 0.4.1: mmk_pose_loss_*, mmk_bce_mean_*; 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
+#define MMK_VERSION 402 /* 0.4.2: arg-max codes of the poolings (mmk_conv_desc.pool_arg, mmk_maxpool2_fwd_arg / _bwd_arg, mmk_unet_desc.keep_full_res); 0.4.1: mmk_pose_loss_*, mmk_bce_mean_*; 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -292,6 +292,11 @@ typedef struct {
     void *pool_y;          /* optional bf16 (B,H/2,W/2,O1): nn.MaxPool2d(2,2) of y1 written by the same
                               pass (forward role, single output; layers for which
                               mmk_conv3x3_pool_fusable() returns 1), else NULL                  */
+    void *pool_arg;        /* optional, with pool_y: (B,H/2,W/2,O1/2) bytes of arg-max codes, one nibble per channel
+                              (channel c in bits 4 (c & 1) of byte c / 2) = position 0..3 of the window's first maximum in
+                              scan order | (maximum > 0) << 2.  When set, y1 is NOT written (may be NULL): the pooled
+                              tensor and the codes are all that the rest of the network and its backward pass
+                              (mmk_maxpool2_bwd_arg) read of this layer's output                  */
 } mmk_conv_desc;
 
 /* 1 when mmk_conv3x3 can write the 2x2 max-pool of this layer's output itself (pool_y). */
@@ -374,6 +379,12 @@ int mmk_conv_first_wgrad(const float *x, int32_t cin, const void *g, const float
 int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *stream);
 int mmk_maxpool2_bwd(const void *d, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
                      float leaky_slope, void *gz, void *stream);
+/* The same pair through arg-max codes (layout: mmk_conv_desc.pool_arg): _fwd_arg also writes the codes, _bwd_arg routes
+ * gy by them instead of re-deriving the arg-max from the full-resolution tensor d (ReLU network: leaky_slope = 0) --
+ * gz is bit-identical to mmk_maxpool2_bwd's, from C/2 + 2C bytes per window instead of 10C.                          */
+int mmk_maxpool2_fwd_arg(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *arg, void *stream);
+int mmk_maxpool2_bwd_arg(const void *arg, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
+                         void *gz, void *stream);
 
 /* nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (icp_weight_policy.py:175-176).
  * _bwd is the adjoint in gather form; relu_src (optional, source-sized) applies
@@ -440,6 +451,9 @@ typedef struct {
                                    the forward, read by the backward -- the caller keeps it in between     */
     size_t workspace_bytes;
     float *mask;                /* (B,H,W) fp32: output of the forward, input of the backward             */
+    int32_t keep_full_res;      /* 1: the encoder blocks whose second convolution pools in the same pass also write
+                                   their pre-pool output (mmk_unet_tensor ids 7, 8; diagnostics).  0: they write the
+                                   pooled tensor and its arg-max codes only -- nothing else reads that output     */
 } mmk_unet_desc;
 
 size_t mmk_unet_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t cin);

@@ -55,7 +55,8 @@ class ConvDesc(ctypes.Structure):
                 ("y2", ctypes.c_void_p), ("relu_src2", ctypes.c_void_p), ("O2", ctypes.c_int32),
                 ("accumulate2", ctypes.c_int32), ("scale2", ctypes.c_float),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32),
-                ("leaky_slope", ctypes.c_float), ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p)]
+                ("leaky_slope", ctypes.c_float), ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("pool_y", ctypes.c_void_p),
+                ("pool_arg", ctypes.c_void_p)]
 
 
 class UNetDesc(ctypes.Structure):
@@ -63,7 +64,8 @@ class UNetDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("cin", ctypes.c_int32),
                 ("x", ctypes.c_void_p), ("pre", ctypes.c_void_p), ("params", ctypes.POINTER(ctypes.c_void_p)),
                 ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("leaky_slope", ctypes.c_float), ("norm", ctypes.c_int32),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("mask", ctypes.c_void_p)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("mask", ctypes.c_void_p),
+                ("keep_full_res", ctypes.c_int32)]
 
 
 FINAL_BWD_WS_FLOATS = 16384        # MMK_FINAL_BWD_WS_FLOATS of include/mmk.h
@@ -147,6 +149,8 @@ def _declare(lib):
         "mmk_conv_first_wgrad": (ctypes.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp, sz, c_vp]),
         "mmk_maxpool2_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_maxpool2_bwd": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, f32, c_vp, c_vp]),
+        "mmk_maxpool2_fwd_arg": (ctypes.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
+        "mmk_maxpool2_bwd_arg": (ctypes.c_int, [c_vp, c_vp, i32, i32, i32, i32, f32, c_vp, c_vp]),
         "mmk_upsample_fwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, c_vp]),
         "mmk_upsample_bwd": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, c_vp, f32, f32, c_vp, c_vp]),
         "mmk_final_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),

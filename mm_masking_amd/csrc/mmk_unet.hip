@@ -423,7 +423,10 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CK, int CM, int RD, bool EPI, bool POOL = false, bool C8 = false>
+// POOL: 0 = no pooling; 1 = the output and its 2x2 max-pool (pool_y); 2 = the max-pool and its arg-max codes (pool_y, pool_arg)
+// only: the full-resolution output is not written at all (the backward pass routes the pooled gradient by the codes,
+// maxpool2_bwd_arg_kernel, and nothing else reads the block's pre-pool output)
+template <int CK, int CM, int RD, bool EPI, int POOL = 0, bool C8 = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
     static_assert(!(EPI && POOL), "the pooled output belongs to the forward pass (no epilogue operands)");
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     constexpr int NW = NS * MT * 64;
     constexpr int RIN = (NIN + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int RW = (NW + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int NST = C8 ? 1 : MT * NT + (POOL ? MT : 0);       // stores per stage
+    constexpr int NST = C8 ? 1 : (POOL == 2 ? 2 * MT : MT * NT + (POOL ? MT : 0));       // stores per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);           // 2 buffers of HT*WT*PK
     bf16 *w_lds = in_tile + 2 * HT * WT * PK;
@@ -663,7 +666,7 @@ ring_done:;
 #undef MMK_RING_STORE
 }
 
-template <int CK, int CM, int RD, bool EPI, bool POOL = false, bool C8 = false>
+template <int CK, int CM, int RD, bool EPI, int POOL = 0, bool C8 = false>
 int launch_conv_ring(const ConvArgs &a, hipStream_t st)
 {
     const size_t smem = ((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
@@ -711,7 +714,8 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
     const bool epi = a.o1.relu_src || a.o1.accumulate || (a.o2.C > 0 && (a.o2.relu_src || a.o2.accumulate));
     if (a.pool_y != nullptr) {
         if constexpr (CK == CM && (CK == 16 || CK == 32)) {   // the encoder's second convs below 64 channels
-            if (!epi && a.o2.C == 0) return launch_conv_ring<CK, CM, RD, false, true>(a, st);
+            if (!epi && a.o2.C == 0)
+                return a.pool_arg != nullptr ? launch_conv_ring<CK, CM, RD, false, 2>(a, st) : launch_conv_ring<CK, CM, RD, false, 1>(a, st);
         }
         mmk::set_error("mmk_conv3x3: pool_y is not supported for this layer (see mmk_conv3x3_pool_fusable)");
         return MMK_ERR_ARG;
@@ -2353,7 +2357,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
 // 2x2 / stride 2 max pooling (nn.MaxPool2d(2,2), icp_weight_policy.py:122-123), NHWC bf16,
 // one thread per (output pixel, 8-channel granule).  Output (H/2, W/2) rounded down, as torch does
 // (the polar 400 x 3360 network input reaches odd sizes: 25 x 105 at the fifth level).
-__global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, int W, int C, bf16 *__restrict__ y)
+// `arg` (optional): (B,H/2,W/2,C/2) bytes, one nibble per channel = position of the first maximum of the window in scan order
+// | (maximum > 0) << 2 -- all the backward pass needs of the full-resolution tensor (maxpool2_bwd_arg_kernel).
+__global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, int W, int C, bf16 *__restrict__ y,
+                                    unsigned *__restrict__ arg)
 {
     const int Ho = H / 2, Wo = W / 2, G = C / 8;
     const size_t n = (size_t)B * Ho * Wo * G;
@@ -2372,6 +2379,59 @@ __global__ void maxpool2_fwd_kernel(const bf16 *__restrict__ x, int B, int H, in
     for (int j = 0; j < 8; ++j)
         o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
     *reinterpret_cast<bf16x8 *>(y + po * C + gc * 8) = o;
+    if (arg != nullptr) {
+        unsigned code = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = (float)v00[j];
+            unsigned a = 0;
+            if ((float)v01[j] > m) { m = (float)v01[j]; a = 1; }
+            if ((float)v10[j] > m) { m = (float)v10[j]; a = 2; }
+            if ((float)v11[j] > m) { m = (float)v11[j]; a = 3; }
+            code |= (a | (m > 0.f ? 4u : 0u)) << (4 * j);
+        }
+        arg[e] = code;          // granule e = (pooled pixel, 8 channels) = 4 bytes of codes
+    }
+}
+
+// maxpool2_bwd_kernel from the arg-max codes of the forward pass instead of the full-resolution tensor (ReLU network: the
+// factor is (maximum > 0 ? scale : 0)): reads C/2 + 2 C bytes per window instead of 10 C, writes the same 8 C.
+__global__ void maxpool2_bwd_arg_kernel(const unsigned *__restrict__ arg, const bf16 *__restrict__ gy, int B, int H, int W, int C,
+                                        float scale, bf16 *__restrict__ gz)
+{
+    const int Ho = H / 2, Wo = W / 2, G = C / 8;
+    const size_t n = (size_t)B * Ho * Wo * G;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int gc = (int)(e % G);
+    const size_t po = e / G;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), b = (int)(po / ((size_t)Wo * Ho));
+    const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + gc * 8;
+    const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    const unsigned code = arg[e];
+    const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gy + po * C + gc * 8);
+    bf16x8 o[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned c = (code >> (4 * j)) & 0xFu;
+        const float gv = (c & 4u) ? (float)g[j] * scale : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k][j] = (bf16)(((unsigned)k == (c & 3u)) ? gv : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x8 *>(gz + base + offs[k]) = o[k];
+    // odd H / W (floor pooling): the last row / column belongs to no window and gets a zero gradient
+    const bf16x8 z8 = {};
+    const bool xr = (W & 1) && xo == Wo - 1, yr = (H & 1) && yo == Ho - 1;
+    if (xr) {
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)C) = z8;
+        *reinterpret_cast<bf16x8 *>(gz + base + (size_t)W * C + 2 * (size_t)C) = z8;
+    }
+    if (yr) {
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C) = z8;
+        *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C + C) = z8;
+        if (xr) *reinterpret_cast<bf16x8 *>(gz + base + 2 * (size_t)W * C + 2 * (size_t)C) = z8;
+    }
 }
 
 // Backward of dropout(relu(.)) -> maxpool in one pass: the pooled gradient goes to the first
@@ -3126,7 +3186,8 @@ extern "C" int mmk_conv3x3_pack_weights_batch(int32_t n, const float *const *W, 
 extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
 {
     MMK_REQUIRE(d != nullptr, "mmk_conv3x3: NULL descriptor");
-    MMK_REQUIRE(d->x1 && d->wpack && d->y1, "mmk_conv3x3: NULL pointer");
+    MMK_REQUIRE(d->x1 && d->wpack && (d->y1 || (d->pool_y && d->pool_arg)), "mmk_conv3x3: NULL pointer");
+    MMK_REQUIRE(d->pool_arg == nullptr || d->pool_y != nullptr, "mmk_conv3x3: pool_arg needs pool_y");
     MMK_REQUIRE(d->B >= 1 && d->H >= 1 && d->W >= 1, "mmk_conv3x3: bad shape");
     const int cin = d->C1 + d->C2, cout = d->O1 + d->O2;
     MMK_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0 && (d->C2 == 0 || d->x2), "mmk_conv3x3: bad input split %d+%d", d->C1, d->C2);
@@ -3142,6 +3203,7 @@ extern "C" int mmk_conv3x3(const mmk_conv_desc *d, void *stream)
     MMK_REQUIRE(d->leaky_slope >= 0.f && d->leaky_slope <= 1.f, "mmk_conv3x3: leaky_slope must be in [0, 1]");
     a.relu = d->relu; a.slope = d->leaky_slope; a.drop_p = d->drop_p; a.seed = d->seed;
     a.pool_y = (bf16 *)d->pool_y;
+    a.pool_arg = (unsigned char *)d->pool_arg;
     return dispatch_conv(a, (hipStream_t)stream);
 }
 
@@ -3374,7 +3436,28 @@ extern "C" int mmk_maxpool2_fwd(const void *x, int32_t B, int32_t H, int32_t W, 
     MMK_REQUIRE(x && y && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_fwd: bad argument");
     const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, H, W, C,
-                       (bf16 *)y);
+                       (bf16 *)y, (unsigned *)nullptr);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_maxpool2_fwd_arg(const void *x, int32_t B, int32_t H, int32_t W, int32_t C, void *y, void *arg, void *stream)
+{
+    MMK_REQUIRE(x && y && arg && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_fwd_arg: bad argument");
+    const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, B, H, W, C,
+                       (bf16 *)y, (unsigned *)arg);
+    MMK_LAUNCH_CHECK();
+    return MMK_OK;
+}
+
+extern "C" int mmk_maxpool2_bwd_arg(const void *arg, const void *gy, int32_t B, int32_t H, int32_t W, int32_t C, float scale,
+                                    void *gz, void *stream)
+{
+    MMK_REQUIRE(arg && gy && gz && B >= 1 && H >= 2 && W >= 2 && C % 8 == 0, "mmk_maxpool2_bwd_arg: bad argument");
+    const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_bwd_arg_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned *)arg,
+                       (const bf16 *)gy, B, H, W, C, scale, (bf16 *)gz);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

@@ -33,6 +33,7 @@ struct Plan {
     int cout[NCONV], cinn[NCONV];               // channel counts of conv k
     // forward tensors
     Tens a_enc[6], d_enc[6], t[6];
+    size_t t_arg[6];                            // arg-max codes of the pooling that produced t[i] (i >= 1): B * rh[i] * rw[i] * ch / 2 bytes
     Tens u[5], a1[5], d1[5], a2[5], d2[5];
     size_t packs[NCONV];                        // packed weights (k = 1..21)
     size_t mask_raw, amax, norm_part;
@@ -95,6 +96,7 @@ bool make_plan(Plan &p, int B, int H, int W, int cin, bool with_scratch)
         p.a_enc[i] = b.tens(B, p.rh[i - 1], p.rw[i - 1], ENC_CH[i]);
         p.d_enc[i] = b.tens(B, p.rh[i - 1], p.rw[i - 1], ENC_CH[i]);
         p.t[i] = b.tens(B, p.rh[i], p.rw[i], ENC_CH[i]);
+        p.t_arg[i] = b.take((size_t)B * p.rh[i] * p.rw[i] * ENC_CH[i] / 2);
     }
     for (int j = 0; j < 5; ++j) {
         const int cs = ENC_CH[4 - j], h = p.rh[4 - j], w = p.rw[4 - j];
@@ -175,7 +177,7 @@ struct ConvCall {
     int relu = 0;
     float drop_p = 0.f;
     unsigned seed = 0;
-    void *pool_y = nullptr;
+    void *pool_y = nullptr, *pool_arg = nullptr;
 };
 
 int conv(const Plan &p, int h, int w, float slope, const ConvCall &c, void *stream)
@@ -186,7 +188,7 @@ int conv(const Plan &p, int h, int w, float slope, const ConvCall &c, void *stre
     d.y1 = c.y1; d.relu_src1 = c.src1; d.O1 = c.O1; d.accumulate1 = c.acc1; d.scale1 = c.scale1;
     d.y2 = c.y2; d.relu_src2 = c.src2; d.O2 = c.O2; d.accumulate2 = c.acc2; d.scale2 = c.scale2;
     d.B = p.B; d.H = h; d.W = w; d.relu = c.relu; d.leaky_slope = slope; d.drop_p = c.drop_p; d.seed = c.seed;
-    d.pool_y = c.pool_y;
+    d.pool_y = c.pool_y; d.pool_arg = c.pool_arg;
     return mmk_conv3x3(&d, stream);
 }
 
@@ -323,10 +325,19 @@ extern "C" int mmk_unet_forward(const mmk_unet_desc *d, void *stream)
         ConvCall c2;
         c2.x1 = at(ws, p.a_enc[i].off); c2.C1 = ch; c2.wpack = at(ws, p.packs[2 * i + 1]); c2.bias = Bk(2 * i + 1);
         c2.y1 = at(ws, p.d_enc[i].off); c2.O1 = ch; c2.relu = 1; c2.drop_p = d->drop_p; c2.seed = ++ctr;
+        // ReLU network: the pooling leaves arg-max codes for the backward pass (mmk_maxpool2_bwd_arg), which then never reads
+        // the block's pre-pool output d_enc[i]; where the second conv pools in the same pass it does not even write it
+        // (desc.keep_full_res: it does, and a pooling pass over it makes the codes -- diagnostics)
         const bool fuse = sl == 0.f && mmk_conv3x3_pool_fusable(ch, ch, B, h, w) != 0;
+        const bool lean = fuse && !d->keep_full_res;
         if (fuse) c2.pool_y = at(ws, p.t[i].off);          // the second conv writes its 2x2 max-pool as well
+        if (lean) { c2.pool_arg = at(ws, p.t_arg[i]); c2.y1 = nullptr; }
         MMK_TRY(conv(p, h, w, sl, c2, stream));
-        if (!fuse) MMK_TRY(mmk_maxpool2_fwd(at(ws, p.d_enc[i].off), B, h, w, ch, at(ws, p.t[i].off), stream));
+        if (sl == 0.f) {
+            if (!lean) MMK_TRY(mmk_maxpool2_fwd_arg(at(ws, p.d_enc[i].off), B, h, w, ch, at(ws, p.t[i].off), at(ws, p.t_arg[i]), stream));
+        } else {
+            MMK_TRY(mmk_maxpool2_fwd(at(ws, p.d_enc[i].off), B, h, w, ch, at(ws, p.t[i].off), stream));
+        }
     }
     // ---- decoder (each block applied twice with shared weights: icp_weight_policy.py:178,182)
     const Tens *cur = &p.t[5];
@@ -521,7 +532,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     const void *g_t = gz;
     for (int i = 5; i >= 1; --i) {
         const int ch = ENC_CH[i], h = p.rh[i - 1], w = p.rw[i - 1];
-        MMK_TRY(mmk_maxpool2_bwd(at(ws, p.d_enc[i].off), g_t, B, h, w, ch, s, sl, at(sc, p.gz_d[i].off), stream));
+        if (sl == 0.f)
+            MMK_TRY(mmk_maxpool2_bwd_arg(at(ws, p.t_arg[i]), g_t, B, h, w, ch, s, at(sc, p.gz_d[i].off), stream));
+        else
+            MMK_TRY(mmk_maxpool2_bwd(at(ws, p.d_enc[i].off), g_t, B, h, w, ch, s, sl, at(sc, p.gz_d[i].off), stream));
         if (can_fuse(2 * i + 1, ch, h, w)) {
             MMK_TRY(bwd_fused(2 * i + 1, ch, at(ws, p.a_enc[i].off), at(sc, p.gz_d[i].off), at(sc, p.gz_a[i].off), h, w));
         } else {

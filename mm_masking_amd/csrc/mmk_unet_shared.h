@@ -32,6 +32,9 @@ struct ConvArgs {
     float drop_p;          // forward dropout on the output (0 = none)
     unsigned seed;
     bf16 *pool_y;          // optional (B,H/2,W/2,COUT): 2x2 max-pool of the output, written by the same pass
+    unsigned char *pool_arg = nullptr;   // with pool_y: (B,H/2,W/2,COUT/2) arg-max codes of the pooling windows, one nibble per
+                                         // channel = position of the first maximum in scan order | (maximum > 0) << 2; the
+                                         // full-resolution output o1.y is then NOT written (may be null)
     // sub-batch launches of dispatch_conv_deep (round 4): the element index of the dropout draws continues where the images in
     // front of this sub-batch end, and the packed weights may be laid out for a wider block than the kernel's own (wpack_mtb =
     // 16-channel tiles per group of the packing, 0 = the kernel's own width)

@@ -57,16 +57,18 @@ def pack_weights_batch(ws, transposed=False):
 
 def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0, out=None, out2=None, split=None,
             relu_src=None, scale=1.0, relu_src2=None, scale2=1.0, accumulate=False, accumulate2=False, pool_out=None,
-            slope=0.0):
+            slope=0.0, pool_arg=None):
     """3x3 / pad 1 convolution on NHWC bf16.  input = concat(x1, x2); output channels
     [0,split) -> out, [split,cout) -> out2 (split=None: single output).  ``pool_out`` (B,H//2,W//2,cout):
     the 2x2 max-pool of the output, written by the same pass (layers for which pool_fusable() holds).
-    ``slope`` > 0: the LeakyReLU variant (forward activation and the relu_src factors, see include/mmk.h)."""
+    ``slope`` > 0: the LeakyReLU variant (forward activation and the relu_src factors, see include/mmk.h).
+    ``pool_arg`` (B,H//2,W//2,cout//2) uint8, with ``pool_out``: the arg-max codes of the pooling windows; the
+    full-resolution output is then NOT written and None is returned (include/mmk.h: mmk_conv_desc.pool_arg)."""
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     O1 = cout if split is None else split
     O2 = cout - O1
-    if out is None:
+    if out is None and pool_arg is None:
         out = torch.empty(B, H, W, O1, dtype=BF16, device=x1.device)
     if O2 > 0 and out2 is None:
         out2 = torch.empty(B, H, W, O2, dtype=BF16, device=x1.device)
@@ -75,8 +77,10 @@ def conv3x3(x1, wpack, cout, bias=None, x2=None, relu=False, drop_p=0.0, seed=0,
                       y2=_p(out2), relu_src2=_p(relu_src2), O2=O2, accumulate2=1 if accumulate2 else 0,
                       scale2=float(scale2), B=B, H=H, W=W, relu=1 if relu else 0, leaky_slope=float(slope),
                       drop_p=float(drop_p),
-                      seed=int(seed) & 0xFFFFFFFF, pool_y=_p(pool_out))
+                      seed=int(seed) & 0xFFFFFFFF, pool_y=_p(pool_out), pool_arg=_p(pool_arg))
     _lib.check(_lib.lib().mmk_conv3x3(ctypes.byref(d), _lib.stream_ptr(x1.device)))
+    if pool_arg is not None:
+        return None
     return (out, out2) if O2 > 0 else out
 
 
@@ -254,6 +258,23 @@ def maxpool2(x):
     y = torch.empty(B, H // 2, W // 2, C, dtype=BF16, device=x.device)
     _lib.check(_lib.lib().mmk_maxpool2_fwd(_p(x), B, H, W, C, _p(y), _sp(x.device)))
     return y
+
+
+def maxpool2_arg(x):
+    """maxpool2 plus the arg-max codes of its windows, (B,H//2,W//2,C//2) uint8 (include/mmk.h: mmk_conv_desc.pool_arg)."""
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=BF16, device=x.device)
+    arg = torch.empty(B, H // 2, W // 2, C // 2, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().mmk_maxpool2_fwd_arg(_p(x), B, H, W, C, _p(y), _p(arg), _sp(x.device)))
+    return y, arg
+
+
+def maxpool2_bwd_arg(arg, gy, H, W, scale):
+    """maxpool2_bwd of the ReLU network from the arg-max codes instead of the full-resolution tensor: (B,H,W,C) gradient."""
+    B, _, _, C = gy.shape
+    gz = torch.empty(B, H, W, C, dtype=BF16, device=gy.device)
+    _lib.check(_lib.lib().mmk_maxpool2_bwd_arg(_p(arg), _p(gy), B, H, W, C, float(scale), _p(gz), _sp(gy.device)))
+    return gz
 
 
 def maxpool2_bwd(d, gy, scale, slope=0.0):
@@ -562,7 +583,8 @@ class _UNetNative(torch.autograd.Function):
         pp = (ctypes.c_void_p * len(P))(*[t.data_ptr() for t in P])
         d = _lib.UNetDesc(B=B, H=H, W=W, cin=cin, x=x.data_ptr(), pre=None if pre is None else pre.data_ptr(), params=pp,
                           drop_p=float(drop_p) if training else 0.0, seed=int(seed) & 0xFFFFFFFF, leaky_slope=float(slope),
-                          norm=1 if norm else 0, workspace=ws.data_ptr(), workspace_bytes=nbytes, mask=mask.data_ptr())
+                          norm=1 if norm else 0, workspace=ws.data_ptr(), workspace_bytes=nbytes, mask=mask.data_ptr(),
+                          keep_full_res=1 if DEBUG is not None else 0)     # (the pre-pool outputs: only diagnostics read them)
         _lib.check(L.mmk_unet_forward(ctypes.byref(d), _sp(dev)))
         if DEBUG is not None:
             def tv(tid):

@@ -1,17 +1,21 @@
 #!/bin/bash
-# Same-box A/B of the whole step: the round-3 tree (exported with `git archive c9bd817` into build_exp/r03 and built there) against
-# this tree, bench.py run alternately in fresh processes, three times each (boxes of the pool differ by +-1.5 %, so numbers
-# from different gpurun calls do not rank builds).  Run on the GPU box from the repository root:  bash scripts/ab_round.sh
+# Same-box A/B of the whole step: another tree (default build_exp/prev = `git archive <commit>` exported and built there; round 4
+# first used build_exp/r03 = the round-3 tree) against this tree, bench.py run alternately in fresh processes, three times each
+# (boxes of the pool differ by +-1.5 %, so numbers from different gpurun calls do not rank builds).  Run on the GPU box from the
+# repository root:  bash scripts/ab_round.sh [other-tree] [tag-of-other] [tag-of-this]
 set -o pipefail
 mkdir -p gpurun_out
+OTHER=${1:-build_exp/prev}
+TA=${2:-prev}
+TB=${3:-this}
 FLAGS="--steps 20 --warmup 3 --no-side --no-cpu-baseline --no-grid --no-parity"
 for rep in 1 2 3; do
-  (cd build_exp/r03 && python3 bench.py $FLAGS 2>/dev/null) > gpurun_out/ab_round_r03_$rep.json || exit 1
-  python3 bench.py $FLAGS 2>/dev/null > gpurun_out/ab_round_r04_$rep.json || exit 1
+  (cd $OTHER && python3 bench.py $FLAGS 2>/dev/null) > gpurun_out/ab_round_${TA}_$rep.json || exit 1
+  python3 bench.py $FLAGS 2>/dev/null > gpurun_out/ab_round_${TB}_$rep.json || exit 1
 done
-python3 - <<'PY'
-import json
-for tag in ("r03", "r04"):
+python3 - $TA $TB <<'PY'
+import json, sys
+for tag in sys.argv[1:3]:
     ms = []
     for rep in (1, 2, 3):
         d = json.load(open("gpurun_out/ab_round_%s_%d.json" % (tag, rep)))
