@@ -614,6 +614,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
             asm volatile("" : "+v"(bs8[r]));
         }
     }
+    // Inverted dropout's factor 1 / keep rides in the bias addition: v = max(fma(acc, dk, bias dk), 0) (dk > 0 commutes with
+    // the ReLU; dk = 1 without dropout, where the fma IS the addition), and the draws then only zero elements -- one
+    // multiplication per output value less in kernels that are bound by vector-instruction issue.
+    const float dk = a.drop_p > 0.f ? dp.inv_keep : 1.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[m][r] *= dk;
+    if constexpr (C8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bs8[r] *= dk;
+    }
 
     // Fill the ring.  Sink stores stand in for the epilogues that have not run yet, so that the
     // first stage meets the same load/store queue as every later one:

@@ -87,4 +87,13 @@ __device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const
     for (int r = 0; r < 4; ++r) sc[r] = (dr[r] >= d.thr) ? d.inv_keep : 0.f;
 }
 
+// the same draws as keep flags (the caller has folded the factor 1 / keep into the value already)
+__device__ __forceinline__ void dropout_keep4(unsigned seed, unsigned e4, const DropoutParams &d, bool (&keep)[4])
+{
+    unsigned dr[4];
+    dropout_draws4(seed, e4, dr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r] = dr[r] >= d.thr;
+}
+
 }  // namespace mmku

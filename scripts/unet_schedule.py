@@ -69,9 +69,15 @@ def schedule(B=32, H=640, W=640, cin0=1):
     for i in range(1, 6):
         conv("enc%d.0" % i, "fwd", i - 1, ENC[i - 1], ENC[i])
         fused_pool = ENC[i] in (16, 32)
-        conv("enc%d.2" % i, "fwd+pool" if fused_pool else "fwd", i - 1, ENC[i], ENC[i], extra_wr=px(i) * ENC[i] * 2 if fused_pool else 0)
-        if not fused_pool:
-            add("maxpool2_fwd_kernel", "enc%d.pool" % i, "fwd", px(i - 1) * ENC[i] * 2, px(i) * ENC[i] * 2)
+        codes = px(i) * ENC[i] // 2         # arg-max codes of the pooling: one nibble per pooled element (round 4)
+        if fused_pool:
+            # the pooling second convolution writes the pooled tensor + codes and NOT its full-resolution output
+            n = px(i - 1)
+            add(conv_kernel(ENC[i], ENC[i]), "enc%d.2" % i, "fwd+pool (pooled + codes only)", n * ENC[i] * 2, px(i) * ENC[i] * 2 + codes,
+                2.0 * 9 * ENC[i] * ENC[i] * n)
+        else:
+            conv("enc%d.2" % i, "fwd", i - 1, ENC[i], ENC[i])
+            add("maxpool2_fwd_kernel", "enc%d.pool" % i, "fwd", px(i - 1) * ENC[i] * 2, px(i) * ENC[i] * 2 + codes)
     for j in range(5):
         cs, lvl = ENC[4 - j], 4 - j
         add("upsample_fwd_kernel", "dec%d.up" % j, "fwd", px(lvl + 1) * 2 * cs * 2, px(lvl) * 2 * cs * 2)
@@ -134,7 +140,7 @@ def schedule(B=32, H=640, W=640, cin0=1):
         ch, lvl = ENC[i], i - 1
         pool_fused = False      # (round 4 tried the pooling adjoint inside the fused launch: slower, scripts/experiments/r04_pool_fused_backward.patch)
         if not pool_fused:
-            add("maxpool2_bwd_kernel", "enc%d.pool" % i, "bwd", px(lvl) * ch * 2 + px(i) * ch * 2, px(lvl) * ch * 2)
+            add("maxpool2_bwd_arg_kernel", "enc%d.pool" % i, "bwd (by the codes)", px(i) * ch // 2 + px(i) * ch * 2, px(lvl) * ch * 2)
         if pool_fused:
             # reads x, the block's output d (for the routing) and the pooled gradient; writes dx
             add("conv_bwd_fused_kernel<16, 16, true>", "enc%d.pool + enc%d.2" % (i, i), "pool bwd + dgrad+wgrad",
