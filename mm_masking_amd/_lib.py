@@ -87,12 +87,15 @@ def build(verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
-    per_file = {}            # (extra flags per source file: none at present)
+    # mmk_unet.hip: MFMA results in VGPRs instead of AGPRs.  The thin-layer kernels are bound by vector-instruction issue and the
+    # compiler's default parks their accumulators in AGPRs, which vector instructions cannot read: every output value then costs
+    # a v_accvgpr_read (4 184 of them in the file, 96 with the option; same arithmetic, same or better occupancy)
+    per_file = {"mmk_unet.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        deps = [src] + common + extra.get(os.path.basename(src), [])
+        deps = [src] + common + extra.get(os.path.basename(src), []) + [os.path.abspath(__file__)]
         if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)):
             jobs.append([hipcc] + flags + per_file.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(o) for o in objs):
