@@ -1586,12 +1586,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdF
     constexpr int NX = HT * WT * GX, NG = HT * WT * GG;
     constexpr int RX = (NX + CONV_THREADS - 1) / CONV_THREADS, RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
     u32x4 rx[RX], rg[RG];
-    auto load_tile = [&](int t) {
+    auto load_tile = [&](int b, int tyi, int txi) {
         int tv = tid;
         asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int tx0 = txi * TW, ty0 = tyi * TH;
         const int pix0 = (b * a.H + ty0) * a.W + tx0;
 #pragma unroll
         for (int i = 0; i < RX; ++i) {
@@ -1640,11 +1638,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdF
     } else {
         t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
     }
-    if (t_first < t_end) load_tile(t_first);
+    // (image, tile row, tile column) of the walk's tiles by increments on the scalar unit instead of four integer divisions per tile
+    const int adv_tx = t_step % tiles_x, adv_ty = (t_step / tiles_x) % tiles_y, adv_b = t_step / tpi;
+    int ld_b = t_first / tpi, ld_ty = (t_first % tpi) / tiles_x, ld_tx = t_first % tiles_x;
+    int cb = ld_b, cty = ld_ty, ctx = ld_tx;
+    if (t_first < t_end) load_tile(ld_b, ld_ty, ld_tx);
     for (int t = t_first; t < t_end; t += t_step) {
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int b = cb;
+        const int tx0 = ctx * TW, ty0 = cty * TH;
         const int pix0 = (b * a.H + ty0) * a.W + tx0;
         const bool ok8 = (ty0 + lrow8) < a.H && (tx0 + lcol8) < a.W;
         __syncthreads();
@@ -1654,8 +1655,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdF
         u32x4 e8_acc = {0u, 0u, 0u, 0u};
         if constexpr (CX == 8) e8_acc = *((ok8 && a.accumulate_dx) ? reinterpret_cast<const u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : &g_zero16);
         {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);
+            if (t + t_step < t_end) {      // the next tile of the walk (past the last one the current tile is loaded again)
+                ld_tx += adv_tx;
+                const int cx = ld_tx >= tiles_x ? 1 : 0;
+                ld_tx -= cx ? tiles_x : 0;
+                ld_ty += adv_ty + cx;
+                const int cy = ld_ty >= tiles_y ? 1 : 0;
+                ld_ty -= cy ? tiles_y : 0;
+                ld_b += adv_b + cy;
+            }
+            load_tile(ld_b, ld_ty, ld_tx);
+            cb = ld_b; cty = ld_ty; ctx = ld_tx;
         }
         // ---- weight gradient: tile rows 0..7, the fragments of row r+1 in flight while row r is consumed
         i32x2 fa[2][2], fb[2][2 * NTW];
