@@ -2255,6 +2255,9 @@ __device__ __forceinline__ void load_row6(const float *__restrict__ xc, int y2, 
     for (int i = 0; i < 6; ++i) v[i] = (float)(bf16)v[i];       // bf16 operands as on the MFMA path
 }
 
+// (LK = the LeakyReLU network, slope > 0: a compile-time switch -- as a run-time test of `slope` the activation of each of the
+// 32 outputs of a thread became its own pair of branches, ~300 instructions beside the 144 packed FMAs)
+template <bool LK>
 __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restrict__ x, int CIN, const float *__restrict__ Wt,
                                                             const float *__restrict__ bias, const float *__restrict__ pre, int B,
                                                             int H, int W, float slope, bf16 *__restrict__ y)
@@ -2297,7 +2300,7 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
         for (int px = 0; px < 4; ++px) {
             bf16x8 o;
 #pragma unroll
-            for (int co = 0; co < 8; ++co) o[co] = (bf16)((slope > 0.f) ? act_leaky(acc[px][co], slope) : fmaxf(acc[px][co], 0.f));
+            for (int co = 0; co < 8; ++co) o[co] = (bf16)(LK ? act_leaky(acc[px][co], slope) : fmaxf(acc[px][co], 0.f));
             *reinterpret_cast<bf16x8 *>(dst + px * 8) = o;
         }
     }
@@ -3433,8 +3436,12 @@ extern "C" int mmk_conv_first(const float *x, int32_t cin, const float *W, const
     const size_t npix = (size_t)B * H * Wd;
     if (Wd % 4 == 0 && npix < (1u << 31)) {
         const unsigned blocks = (unsigned)std::min<size_t>((npix / 4 + 255) / 256, 4096);
-        hipLaunchKernelGGL(conv_first_x4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd,
-                           leaky_slope, (bf16 *)y);
+        if (leaky_slope > 0.f)
+            hipLaunchKernelGGL(conv_first_x4_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd,
+                               leaky_slope, (bf16 *)y);
+        else
+            hipLaunchKernelGGL(conv_first_x4_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cin, W, bias, pre, B, H, Wd,
+                               leaky_slope, (bf16 *)y);
         MMK_LAUNCH_CHECK();
         return MMK_OK;
     }
