@@ -2602,7 +2602,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const bf16 *__restric
 // compacted to the front.  Every output row in reach is then summed along x once (NW unconditional
 // 16-byte loads) and added to the one or two source rows it was interpolated from.  Wider runs
 // (factors < 2) take the generic loop.
-template <bool POW2>
+template <bool POW2, bool LK>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16 *__restrict__ gy, int Hs, int Ws, int C, int Ho, int Wo,
                                                            float rh, float rw, int lg, const bf16 *__restrict__ relu_src,
                                                            float scale, float slope, bf16 *__restrict__ gx)
@@ -2705,7 +2705,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16 *__restric
             unpack8(*reinterpret_cast<const u32x4 *>(relu_src + po), sv);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                acc[r][j] = (slope > 0.f) ? acc[r][j] * bwd_factor_leaky(sv[j], scale, slope) : ((sv[j] > 0.f) ? acc[r][j] * scale : 0.f);
+                acc[r][j] = LK ? acc[r][j] * bwd_factor_leaky(sv[j], scale, slope) : ((sv[j] > 0.f) ? acc[r][j] * scale : 0.f);
         }
         *reinterpret_cast<u32x4 *>(gx + po) = pack8(acc[r]);
     }
@@ -2728,6 +2728,7 @@ __global__ void final_fwd_kernel(const bf16 *__restrict__ x, const float *__rest
 // grid: x strides over the pixels of one image, y = image.  coef (optional, 2 floats per image) carries the
 // adjoint of the mask's amax normalisation (see mask_norm_*): the gradient w.r.t. the raw sigmoid output is
 // g * (1 / a) + (m == a ? t : 0)  with a = amax, t = -(sum g m_n) / a / count(m == a).
+template <bool LK>        // LK: the LeakyReLU network (slope > 0), a compile-time switch (no branch per value)
 __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ mask, const float *__restrict__ gmask,
                                                         size_t npix_per, const float *__restrict__ coef, float scale, float slope,
@@ -2769,7 +2770,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const bf16 *__restrict__
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xv = (float)v[u][j];
-                o[j] = (bf16)((slope > 0.f) ? gl * wv8[j] * bwd_factor_leaky(xv, scale, slope) : ((xv > 0.f) ? gl * wv8[j] * scale : 0.f));
+                o[j] = (bf16)(LK ? gl * wv8[j] * bwd_factor_leaky(xv, scale, slope) : ((xv > 0.f) ? gl * wv8[j] * scale : 0.f));
                 acc[j] += gl * xv;
             }
             acc[8] += gl;
@@ -3562,12 +3563,16 @@ extern "C" int mmk_upsample_bwd(const void *gy, int32_t B, int32_t Hs, int32_t W
     MMK_REQUIRE(Hs <= 65535 && B <= 65535, "mmk_upsample_bwd: shape exceeds the launch grid");
     const UpGeom ug = up_geom(Hs, Ws, C, Ho, Wo);
     const dim3 grid(nblk((size_t)Ws * (C / 8), 256), (Hs + UP_ROWS - 1) / UP_ROWS, B);
-    if (ug.lg >= 0)
-        hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
-                           ug.rh, ug.rw, ug.lg, (const bf16 *)relu_src, scale, leaky_slope, (bf16 *)gx);
-    else
-        hipLaunchKernelGGL(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo,
-                           ug.rh, ug.rw, 0, (const bf16 *)relu_src, scale, leaky_slope, (bf16 *)gx);
+#define MMK_UPB(P2, LKV, LG)                                                                                                   \
+    hipLaunchKernelGGL((upsample_bwd_kernel<P2, LKV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16 *)gy, Hs, Ws, C, Ho, Wo, \
+                       ug.rh, ug.rw, LG, (const bf16 *)relu_src, scale, leaky_slope, (bf16 *)gx)
+    const bool lkv = leaky_slope > 0.f;
+    if (ug.lg >= 0) {
+        if (lkv) MMK_UPB(true, true, ug.lg); else MMK_UPB(true, false, ug.lg);
+    } else {
+        if (lkv) MMK_UPB(false, true, 0); else MMK_UPB(false, false, 0);
+    }
+#undef MMK_UPB
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -3586,8 +3591,12 @@ extern "C" int mmk_final_bwd(const void *x, const float *w, const float *mask, c
 {
     MMK_REQUIRE(x && w && mask && gmask && gx && dW && db && ws && npix >= 1, "mmk_final_bwd: bad argument");
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)npix + 255) / 256, 512);
-    hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
-                       (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, ws);
+    if (leaky_slope > 0.f)
+        hipLaunchKernelGGL(final_bwd_kernel<true>, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
+                           (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, ws);
+    else
+        hipLaunchKernelGGL(final_bwd_kernel<false>, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x, w, mask, gmask,
+                           (size_t)npix, (const float *)nullptr, scale, leaky_slope, (bf16 *)gx, ws);
     MMK_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_bwd_reduce_kernel, dim3(1), dim3(288), 0, (hipStream_t)stream, ws, (int)blocks, dW, db);
     MMK_LAUNCH_CHECK();
@@ -3622,8 +3631,12 @@ extern "C" int mmk_final_bwd_normalized(const void *x, const float *w, const flo
     // ~512 blocks in all (9 partial sums per block; per * B <= 512 + B <= MMK_FINAL_BWD_WS_FLOATS / 9 for B <= 1200)
     const unsigned per = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)npix_per + 255) / 256, (512 + B - 1) / B));
     MMK_REQUIRE((size_t)per * B * 9 <= MMK_FINAL_BWD_WS_FLOATS, "mmk_final_bwd_normalized: batch too large for the reduction workspace");
-    hipLaunchKernelGGL(final_bwd_kernel, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
-                       scale, leaky_slope, (bf16 *)gx, ws);
+    if (leaky_slope > 0.f)
+        hipLaunchKernelGGL(final_bwd_kernel<true>, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
+                           scale, leaky_slope, (bf16 *)gx, ws);
+    else
+        hipLaunchKernelGGL(final_bwd_kernel<false>, dim3(per, B), dim3(256), 0, st, (const bf16 *)x, w, mask, gmask_n, (size_t)npix_per, coef,
+                           scale, leaky_slope, (bf16 *)gx, ws);
     MMK_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_bwd_reduce_kernel, dim3(1), dim3(288), 0, st, ws, (int)(per * B), dW, db);
     MMK_LAUNCH_CHECK();
