@@ -328,19 +328,43 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(const float *__restr
     const float wx = ix - x0, wy = iy - y0;
     const float ex = 1.0f - wx, sy = 1.0f - wy;
     const int xi = (int)x0, yi = (int)y0;
+    // The gather is bound by the number of load instructions (64 scattered addresses each), not by bytes: the two taps of a
+    // row are neighbours in memory, so each row of each image is ONE 8-byte load (4-byte aligned) instead of two 4-byte ones, all
+    // four issued back to back; the zero padding is applied as selects afterwards.  Same products, same order of additions as
+    // tap_polar() per tap.  (xi >= 0 because u >= 0; xi = R - 1 shifts the pair one cell left and takes its second element.)
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+    const int xa = min(max(xi, 0), R - 2);
+    const bool shifted = xi > xa;                   // xi == R - 1
+    int roff[2];
+    bool okr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int yk = yi + k;
+        okr[k] = !(yk < 0 || yk >= rows);
+        int r = yk;
+        if (wrap) r = (yk == 0) ? (A - 1) : ((yk == A + 1) ? 0 : yk - 1);
+        roff[k] = min(max(r, 0), A - 1) * R + xa;
+    }
+    const bool okx0 = xi >= 0 && xi < R, okx1 = xi + 1 >= 0 && xi + 1 < R;
     const float *img = polar + (size_t)b * A * R;
-    const float out = tap_polar(img, A, R, yi, xi, wrap) * (sy * ex) + tap_polar(img, A, R, yi, xi + 1, wrap) * (sy * wx) +
-                      tap_polar(img, A, R, yi + 1, xi, wrap) * (wy * ex) +
-                      tap_polar(img, A, R, yi + 1, xi + 1, wrap) * (wy * wx);
-    cart[(size_t)b * W * W + pix] = out;
+    const float *img2 = polar2 != nullptr ? polar2 + (size_t)b * A * R : img;
+    f32x2u p1[2], p2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) p1[k] = *reinterpret_cast<const f32x2u *>(img + roff[k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) p2[k] = *reinterpret_cast<const f32x2u *>(img2 + roff[k]);
+    float t1[4], t2[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        t1[2 * k] = (okr[k] && okx0) ? (shifted ? p1[k].y : p1[k].x) : 0.0f;
+        t1[2 * k + 1] = (okr[k] && okx1) ? p1[k].y : 0.0f;
+        t2[2 * k] = (okr[k] && okx0) ? (shifted ? p2[k].y : p2[k].x) : 0.0f;
+        t2[2 * k + 1] = (okr[k] && okx1) ? p2[k].y : 0.0f;
+    }
+    cart[(size_t)b * W * W + pix] = t1[0] * (sy * ex) + t1[1] * (sy * wx) + t1[2] * (wy * ex) + t1[3] * (wy * wx);
     // a second image on the same grid (the dataset resamples the FFT and the CFAR image with the same
     // azimuths, icp_weight_dataset.py:350-352): the coordinates and tap weights are shared
-    if (polar2 != nullptr) {
-        const float *img2 = polar2 + (size_t)b * A * R;
-        cart2[(size_t)b * W * W + pix] =
-            tap_polar(img2, A, R, yi, xi, wrap) * (sy * ex) + tap_polar(img2, A, R, yi, xi + 1, wrap) * (sy * wx) +
-            tap_polar(img2, A, R, yi + 1, xi, wrap) * (wy * ex) + tap_polar(img2, A, R, yi + 1, xi + 1, wrap) * (wy * wx);
-    }
+    if (polar2 != nullptr) cart2[(size_t)b * W * W + pix] = t2[0] * (sy * ex) + t2[1] * (sy * wx) + t2[2] * (wy * ex) + t2[3] * (wy * wx);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -18,3 +18,4 @@ print("extract_pc_padded %.1f us" % timeit(lambda: ru.extract_pc_padded(cf, 0.05
 print("polar_to_cart %.1f us" % timeit(lambda: ru.radar_polar_to_cartesian_diff(fft, az, 0.0596)))
 cart = ru.radar_polar_to_cartesian_diff(fft, az, 0.0596).unsqueeze(1).contiguous()
 print("channel_minmax %.1f us" % timeit(lambda: uh.channel_minmax(cart)))
+print("polar_to_cart pair %.1f us" % timeit(lambda: ru._polar_to_cart_pair(fft, cf, az, 0.0596)))
