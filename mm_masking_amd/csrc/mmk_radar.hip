@@ -13,6 +13,7 @@ constexpr int RT = 256;  // threads per block for the row kernels
 
 // Block-wide exclusive scan of one double per thread (RT threads); returns the exclusive
 // prefix of `v`, *total gets the block sum.  `sm` holds RT/64 doubles.
+template <int NTHR = RT>
 __device__ __forceinline__ double block_excl_scan(double v, double *sm, double *total)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -26,7 +27,7 @@ __device__ __forceinline__ double block_excl_scan(double v, double *sm, double *
     __syncthreads();
     double base = 0.0, tot = 0.0;
 #pragma unroll
-    for (int w = 0; w < RT / 64; ++w) {
+    for (int w = 0; w < NTHR / 64; ++w) {
         if (w < wv) base += sm[w];
         tot += sm[w];
     }
@@ -61,30 +62,33 @@ __device__ __forceinline__ int block_excl_scan_i(int v, int *sm, int *total)
 // R2 cfar_mask (radar_utils.py:29-69).  One block per azimuth row: the row is staged in
 // LDS, an fp64 prefix sum gives every 50-cell window sum exactly rounded to fp32, and the
 // mask row is written back coalesced: one read + one write of the image.
-__global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__ raw, int R, int w2, int guard,
+// (CFAR_T = 512 threads per row: the 40 KB row buffer admits four blocks per CU, and with 256 threads each that was 16 waves per
+// CU in a launch that is load -> scan -> compute -> store latency from end to end; 32 waves hide twice as much of it)
+constexpr int CFAR_T = 512;
+__global__ __launch_bounds__(CFAR_T) void cfar_mask_kernel(const float *__restrict__ raw, int R, int w2, int guard,
                                                        int mincol, int maxcol, float a_th, float b_th, int diff,
                                                        float steep, float *__restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *cs = reinterpret_cast<double *>(smem);                 // R + 1
     float *row = reinterpret_cast<float *>(cs + (R + 1));          // R
-    __shared__ double wsum[RT / 64];
+    __shared__ double wsum[CFAR_T / 64];
     const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * R;
     // (16-byte loads / stores were tried in round 4: no change, 107 -> 112 us -- the kernel is bound by the latency of one row per
     // block at four blocks per CU (40 KB of LDS each), not by the width of its accesses)
-    for (int c = threadIdx.x; c < R; c += RT) row[c] = raw[base + c];
+    for (int c = threadIdx.x; c < R; c += CFAR_T) row[c] = raw[base + c];
     __syncthreads();
-    const int L = (R + RT - 1) / RT;
+    const int L = (R + CFAR_T - 1) / CFAR_T;
     const int c0 = min(R, (int)threadIdx.x * L), c1 = min(R, c0 + L);
     double s = 0.0;
     for (int c = c0; c < c1; ++c) s += (double)row[c];
     double tot;
-    double run = block_excl_scan(s, wsum, &tot);
+    double run = block_excl_scan<CFAR_T>(s, wsum, &tot);
     for (int c = c0; c < c1; ++c) {
         cs[c] = run;
         run += (double)row[c];
     }
-    if (threadIdx.x == RT - 1) cs[R] = tot;
+    if (threadIdx.x == CFAR_T - 1) cs[R] = tot;
     __syncthreads();
     auto cell = [&](int c) -> float {
         float th = 1000.0f;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(RT) void cfar_mask_kernel(const float *__restrict__
         }
         return m;
     };
-    for (int c = threadIdx.x; c < R; c += RT) mask[base + c] = cell(c);
+    for (int c = threadIdx.x; c < R; c += CFAR_T) mask[base + c] = cell(c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -631,7 +635,7 @@ extern "C" int mmk_cfar_mask(const float *raw, int32_t B, int32_t A, int32_t R, 
     MMK_REQUIRE(smem <= 160 * 1024 - 64, "mmk_cfar_mask: R=%d does not fit the 160 KB LDS row buffer", R);
     if (smem > 64 * 1024)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)cfar_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(cfar_mask_kernel, dim3(A, B), dim3(RT), smem, (hipStream_t)stream, raw, R, w2, guard, mincol,
+    hipLaunchKernelGGL(cfar_mask_kernel, dim3(A, B), dim3(CFAR_T), smem, (hipStream_t)stream, raw, R, w2, guard, mincol,
                        maxcol, a_thresh, b_thresh, diff, steep_fact, mask);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
