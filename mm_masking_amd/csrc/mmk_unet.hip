@@ -1291,12 +1291,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     constexpr int NG = TH * TW * GPG;
     constexpr int RG = (NG + CONV_THREADS - 1) / CONV_THREADS;
     u32x4 rin[RIN], rg[RG];
-    auto load_tile = [&](int t) {
+    auto load_tile = [&](int b, int tyi, int txi) {
         int tv = tid;                       // opaque: per-granule offsets are recomputed, not kept live
         asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int tx0 = txi * TW, ty0 = tyi * TH;
         const int pix0 = (b * a.H + ty0) * a.W + tx0;
 #pragma unroll
         for (int i = 0; i < RIN; ++i) {
@@ -1352,14 +1350,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     } else {
         t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
     }
-    if (t_first < t_end) load_tile(t_first);
+    // (the walk's (image, tile row, tile column) by scalar increments, as in conv_bwd_fused_kernel: no integer division per tile)
+    const int adv_tx = t_step % tiles_x, adv_ty = (t_step / tiles_x) % tiles_y, adv_b = t_step / tpi;
+    int ld_b = t_first / tpi, ld_ty = (t_first % tpi) / tiles_x, ld_tx = t_first % tiles_x;
+    if (t_first < t_end) load_tile(ld_b, ld_ty, ld_tx);
     for (int t = t_first; t < t_end; t += t_step) {
         __syncthreads();
         store_tile();
         __syncthreads();
         {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);
+            if (t + t_step < t_end) {      // (past the last tile the current one is loaded again: the loads stay unconditional)
+                ld_tx += adv_tx;
+                const int cx = ld_tx >= tiles_x ? 1 : 0;
+                ld_tx -= cx ? tiles_x : 0;
+                ld_ty += adv_ty + cx;
+                const int cy = ld_ty >= tiles_y ? 1 : 0;
+                ld_ty -= cy ? tiles_y : 0;
+                ld_b += adv_b + cy;
+            }
+            load_tile(ld_b, ld_ty, ld_tx);
         }
         // fragments of tile row r+1 are fetched from LDS while the matrix cores consume row r; the
         // rows are unrolled so that every read carries its row offset as an immediate
@@ -1843,12 +1852,10 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
     u32x4 rin[RIN], rg[RG];
     // `tv` is the thread index behind an opaque asm: everything derived from it is recomputed per tile
     // (a few VALU instructions) instead of being hoisted out of the tile loop into ~50 live registers
-    auto load_tile = [&](int t) {
+    auto load_tile = [&](int b, int tyi, int txi) {
         int tv = tid;
         asm volatile("" : "+v"(tv));
-        const int b = t / tpi, tr = t - b * tpi;
-        const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * TW, ty0 = tyi * TH;
+        const int tx0 = txi * TW, ty0 = tyi * TH;
         const int c0 = chunk * CK;
         const bool in1 = c0 < a.C1;                     // a 64-channel chunk lies in one of the two inputs
         const bf16 *xb = in1 ? a.x1 : a.x2;
@@ -1902,14 +1909,25 @@ __global__ __launch_bounds__(WGD_THREADS) void conv3x3_wgrad_deep_kernel(const W
     } else {
         t_first = blockIdx.x; t_step = gridDim.x; t_end = total_tiles;
     }
-    if (t_first < t_end) load_tile(t_first);
+    // (the walk's (image, tile row, tile column) by scalar increments, as in conv_bwd_fused_kernel: no integer division per tile)
+    const int adv_tx = t_step % tiles_x, adv_ty = (t_step / tiles_x) % tiles_y, adv_b = t_step / tpi;
+    int ld_b = t_first / tpi, ld_ty = (t_first % tpi) / tiles_x, ld_tx = t_first % tiles_x;
+    if (t_first < t_end) load_tile(ld_b, ld_ty, ld_tx);
     for (int t = t_first; t < t_end; t += t_step) {
         __syncthreads();
         store_tile();
         __syncthreads();
         {
-            const int nt = t + t_step;
-            load_tile(nt < t_end ? nt : t);       // (clamped: the loads stay unconditional)
+            if (t + t_step < t_end) {      // (past the last tile the current one is loaded again: the loads stay unconditional)
+                ld_tx += adv_tx;
+                const int cx = ld_tx >= tiles_x ? 1 : 0;
+                ld_tx -= cx ? tiles_x : 0;
+                ld_ty += adv_ty + cx;
+                const int cy = ld_ty >= tiles_y ? 1 : 0;
+                ld_ty -= cy ? tiles_y : 0;
+                ld_b += adv_b + cy;
+            }
+            load_tile(ld_b, ld_ty, ld_tx);
         }
         // double-buffered fragment registers; every read carries its offset as an immediate (~100 distinct
         // addresses would otherwise be hoisted into registers and spilled)
