@@ -2338,10 +2338,14 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
         float acc[80];
 #pragma unroll
         for (int i = 0; i < 80; ++i) acc[i] = 0.f;
-        // operands of the next quad are in flight while the current one is accumulated
+        // Operands of the next quad are in flight while the current one is accumulated.  The image rows are fetched RAW (six
+        // floats per row + a validity mask) and normalised / rounded to bf16 only when their quad is consumed: rounding them
+        // inside the fetch (rounds 1-3) was a use of the loads right behind their issue -- every round waited for the memory
+        // latency of its "prefetch" with 8 waves per CU to hide it.
         bf16x8 gv[4], gn[4];
-        float v[3][6], vn[3][6];
-        auto fetch = [&](int e, bf16x8 (&go)[4], float (&vo)[3][6]) {
+        float rv[3][6], rn[3][6];
+        unsigned mv = 0, mn = 0;                    // bit 6 dy + i: element i of row dy lies inside the image
+        auto fetch = [&](int e, bf16x8 (&go)[4], float (&ro)[3][6], unsigned &mo) {
             const int q = e % Wq, by = e / Wq;
             const int yy = by % H, b = by / H;
             const int x0 = q * 4;
@@ -2349,14 +2353,34 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
             const bf16 *gp = g + ((size_t)by * W + x0) * 8;
 #pragma unroll
             for (int px = 0; px < 4; ++px) go[px] = *reinterpret_cast<const bf16x8 *>(gp + px * 8);
+            unsigned m = 0;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) load_row6(xc, yy + dy - 1, x0, H, W, psub, prcp, vo[dy]);
+            for (int dy = 0; dy < 3; ++dy) {
+                const int y2 = yy + dy - 1;
+                const bool rok = y2 >= 0 && y2 < H;
+                const float *row = xc + (size_t)(rok ? y2 : yy) * W;          // (clamped: the loads stay unconditional)
+                const bool lok = x0 > 0, hok = x0 + 4 < W;
+                const float4 mid = *reinterpret_cast<const float4 *>(row + x0);
+                ro[dy][0] = row[lok ? x0 - 1 : x0];
+                ro[dy][1] = mid.x; ro[dy][2] = mid.y; ro[dy][3] = mid.z; ro[dy][4] = mid.w;
+                ro[dy][5] = row[hok ? x0 + 4 : x0 + 3];
+                m |= (rok ? ((lok ? 1u : 0u) | 0x1Eu | (hok ? 0x20u : 0u)) : 0u) << (6 * dy);
+            }
+            mo = m;
         };
         int e = blockIdx.x * blockDim.x + threadIdx.x;
-        if (e < nq) fetch(e, gv, v);
+        if (e < nq) fetch(e, gv, rv, mv);
         for (; e < nq; e += stride) {
             const int en = e + stride;
-            if (en < nq) fetch(en, gn, vn);
+            fetch(en < nq ? en : e, gn, rn, mn);          // (past the end: the current quad again, unused)
+            float v[3][6];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float t = (rv[dy][i] - psub) * prcp;
+                    v[dy][i] = ((mv >> (6 * dy + i)) & 1u) ? (float)(bf16)t : 0.f;       // bf16 operands as on the MFMA path
+                }
             float gf[4][8];
 #pragma unroll
             for (int px = 0; px < 4; ++px)
@@ -2378,7 +2402,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_x4_kernel(const float *_
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int i = 0; i < 6; ++i) v[dy][i] = vn[dy][i];
+                for (int i = 0; i < 6; ++i) rv[dy][i] = rn[dy][i];
+            mv = mn;
         }
 #pragma unroll
         for (int i = 0; i < 80; ++i) {

@@ -13,6 +13,9 @@ L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 print("conv_first %.1f us" % timeit(lambda: uh.conv_first(x, w0, b0)))
 print("conv_first_wgrad %.1f us" % timeit(lambda: uh.conv_first_wgrad(x, g, None, dw, db)))
+import hashlib
+torch.cuda.synchronize()
+print("conv_first_wgrad md5", hashlib.md5(dw.cpu().numpy().tobytes() + db.cpu().numpy().tobytes()).hexdigest()[:12])
 for H, C in [(640, 16), (320, 32)]:
     s = rnd(B, H // 2, H // 2, C); gy = rnd(B, H, H, C)
     print("up %d c%d fwd %.1f bwd %.1f us" % (H, C, timeit(lambda: uh.upsample(s, H, H)), timeit(lambda: uh.upsample_bwd(gy, H // 2, H // 2, relu_src=s, scale=1.05))))
