@@ -2286,6 +2286,80 @@ __global__ __launch_bounds__(256) void conv_first_x4_kernel(const float *__restr
     for (int co = 0; co < 8; ++co) bs[co] = bias ? bias[co] : 0.f;
     const int Wq = W >> 2;
     const int nq = B * H * Wq;
+    const int stride = gridDim.x * blockDim.x;
+    // One input plane (the reference's default, fft only): the rows of the NEXT quad of the thread's walk are fetched raw (+ a
+    // validity mask) while the current one is computed -- as in conv_first_wgrad_x4_kernel; with several planes the rows are
+    // loaded where they are used (the general loop below).
+    if (CIN == 1) {
+        const float psub = pre ? pre[0] : 0.f, prcp = pre ? pre[1] : 1.f;
+        float rv[3][6], rn[3][6];
+        unsigned mv = 0, mn = 0;
+        auto fetch = [&](int e, float (&ro)[3][6], unsigned &mo) {
+            const int q = e % Wq, by = e / Wq;
+            const int yy = by % H, b = by / H;
+            const int x0 = q * 4;
+            const float *xc = x + (size_t)b * H * W;
+            unsigned m = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int y2 = yy + dy - 1;
+                const bool rok = y2 >= 0 && y2 < H;
+                const float *row = xc + (size_t)(rok ? y2 : yy) * W;
+                const bool lok = x0 > 0, hok = x0 + 4 < W;
+                const float4 mid = *reinterpret_cast<const float4 *>(row + x0);
+                ro[dy][0] = row[lok ? x0 - 1 : x0];
+                ro[dy][1] = mid.x; ro[dy][2] = mid.y; ro[dy][3] = mid.z; ro[dy][4] = mid.w;
+                ro[dy][5] = row[hok ? x0 + 4 : x0 + 3];
+                m |= (rok ? ((lok ? 1u : 0u) | 0x1Eu | (hok ? 0x20u : 0u)) : 0u) << (6 * dy);
+            }
+            mo = m;
+        };
+        int e = blockIdx.x * blockDim.x + threadIdx.x;
+        if (e < nq) fetch(e, rv, mv);
+        for (; e < nq; e += stride) {
+            const int en = e + stride;
+            fetch(en < nq ? en : e, rn, mn);
+            const int q = e % Wq, by = e / Wq;
+            const int x0 = q * 4;
+            float acc[4][8];
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc[px][co] = bs[co];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float t = (rv[dy][i] - psub) * prcp;
+                    v[i] = ((mv >> (6 * dy + i)) & 1u) ? (float)(bf16)t : 0.f;       // bf16 operands as on the MFMA path
+                }
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        const float w = Wt[co * 9 + dy * 3 + tx];
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[px][co] = __builtin_fmaf(v[px + tx], w, acc[px][co]);
+                    }
+                }
+            }
+            bf16 *dst = y + ((size_t)by * W + x0) * 8;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 o;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) o[co] = (bf16)(LK ? act_leaky(acc[px][co], slope) : fmaxf(acc[px][co], 0.f));
+                *reinterpret_cast<bf16x8 *>(dst + px * 8) = o;
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rv[dy][i] = rn[dy][i];
+            mv = mn;
+        }
+        return;
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += gridDim.x * blockDim.x) {
         const int q = e % Wq, by = e / Wq;
         const int yy = by % H, b = by / H;
