@@ -1324,6 +1324,22 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
     active_out[b] = (sqrt(nrm) < (double)tol) ? 0 : 1;
 }
 
+// The head of a forward call in ONE launch: nearest-neighbour keys armed (both buffers), status word cleared, every pair
+// active, T_hist[0] = T_init, the zero-row representatives reset -- five copy / fill launches of 3-6 us each before.
+__global__ __launch_bounds__(256) void icp_init_kernel(unsigned long long *__restrict__ keys, size_t nkeys, int32_t *__restrict__ status,
+                                                       int32_t *__restrict__ active0, const float *__restrict__ T_init,
+                                                       float *__restrict__ T0, int32_t *__restrict__ zrep, int B, int N)
+{
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < nkeys; i += stride) keys[i] = ~0ull;
+    if (i0 < 16) status[i0] = 0;
+    if (i0 < (size_t)B) {
+        active0[i0] = 1;
+        if (zrep != nullptr) zrep[i0] = N;
+    }
+    if (i0 < (size_t)B * 16) T0[i0] = T_init[i0];
+}
+
 __global__ void fill_i32_kernel(int32_t *p, int n, int32_t v)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1772,14 +1788,11 @@ int run_forward(const mmk_icp_params *p, const float *src, const float *tgt, con
     const int nblk = (N + ACC_THREADS - 1) / ACC_THREADS;
     const float k = p->loss_k, k2 = p->loss_k * p->loss_k, trim2 = p->trim_dist * p->trim_dist;
     int k_done = 0;
-    MMK_CHECK_HIP(hipMemsetAsync(w.packed, 0xFF, sizeof(unsigned long long) * (size_t)2 * B * N, st));
-    MMK_CHECK_HIP(hipMemsetAsync(w.status, 0, sizeof(int32_t) * 16, st));
+    // (keys, status word, zero-row representatives: icp_init_kernel in mmk_icp_forward)
     const bool use_grid = p->nn_method == MMK_NN_GRID;
     const int nn_pts = NN_THREADS * pl.P;
     const bool dedup = !use_grid && pl.nsb <= 0xfff && B < (1 << 19);
     if (dedup) {
-        hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.zrep, B, N);
-        MMK_LAUNCH_CHECK();
         hipLaunchKernelGGL(src_zero_scan_kernel, dim3(pl.nsb, B), dim3(NN_THREADS), 0, st, src, N, nn_pts, pl.nsb, w.allzero, w.zrep);
         MMK_LAUNCH_CHECK();
         hipLaunchKernelGGL(src_units_kernel, dim3(1), dim3(64), 0, st, w.allzero, w.zrep, B, pl.nsb, nn_pts, pl.ucap, w.ulist, w.ucnt);
@@ -1992,9 +2005,13 @@ extern "C" int mmk_icp_forward(const mmk_icp_params *p, const float *source, con
                            w.tdec, NN_COARSE_STRIDE);
         MMK_LAUNCH_CHECK();
     }
-    MMK_CHECK_HIP(hipMemcpyAsync(T_hist, T_init, sizeof(float) * B * 16, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, active_hist, B, 1);
-    MMK_LAUNCH_CHECK();
+    {
+        const size_t nkeys = (size_t)2 * B * p->N;
+        const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((nkeys + 255) / 256, (size_t)(B * 16 + 255) / 256), 2048);
+        hipLaunchKernelGGL(icp_init_kernel, dim3(blocks), dim3(256), 0, st, w.packed, nkeys, w.status, active_hist, T_init, T_hist, w.zrep, B,
+                           p->N);
+        MMK_LAUNCH_CHECK();
+    }
     if (p->dim == 2 && p->icp_type == MMK_ICP_PT2PT)
         rc = run_forward<2, MMK_ICP_PT2PT>(p, source, target, weight, T_hist, idx_hist, delta_hist, A_hist, active_hist, w, iters_run, st);
     else if (p->dim == 2)
