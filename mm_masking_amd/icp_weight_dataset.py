@@ -145,7 +145,7 @@ class ICPWeightDataset(torch.utils.data.Dataset):
         (``fft_u8``, ``cfar_u8``, ``azimuths`` in ``loc_data``); ``finish_batch`` then does bytes / 255 and ONE batched
         polar -> Cartesian launch for the whole batch on the device.  ``DeviceLoader`` wraps both steps and stages batch
         i + 1 on a side stream while batch i trains.  Finished batches are equal to ``default_collate`` of the default
-        mode's items (tests/test_round3_cpu.py, tests/test_gpu_round3.py).
+        mode's items (tests/test_loader_cpu.py, tests/test_gpu_loader.py).
     """
 
     def __init__(self, loc_pairs, params=None, dataset_type="train", data_dir="../data"):
@@ -547,7 +547,7 @@ class DeviceLoader:
     and the main process's unpickling (measured 0.45 k items/s against the threads' rate in gpurun_out/r03_loader.json).
     ``mode="processes"``: torch's DataLoader with ``num_workers`` worker processes running the CPU-only ``__getitem__`` and
     pinned collation, as upstream.  Same batches either way, up to the rounding of the augmentation's cloud rotation,
-    which the thread mode leaves to the device (tests/test_round3_cpu.py, tests/test_gpu_round3.py)."""
+    which the thread mode leaves to the device (tests/test_loader_cpu.py, tests/test_gpu_loader.py)."""
 
     def __init__(self, dataset, batch_size, device, num_workers=4, shuffle=False, drop_last=False, prefetch_factor=2,
                  persistent_workers=True, mode="threads", passes=1, seed=None):

@@ -4,6 +4,7 @@ Navtech-format PNG rows (8 timestamp bytes, 2 encoder bytes, 1 pad byte, 3360 po
 import os
 
 import numpy as np
+import torch
 
 from mm_masking_amd import icp_weight_dataset as ds
 from mm_masking_amd import synthetic
@@ -45,3 +46,43 @@ def write_synthetic_export(root, n, n_scan=4000, m_valid=20000, first=9000):
     np.savez(os.path.join(pdir, "index.npz"), loc_stamp=loc_stamp, map_stamp=map_stamp,
              T_gt=np.tile(np.eye(4), (n, 1, 1)), T_map_sensor_robot=np.eye(4))
     return [[map_seq, loc_seq]]
+
+
+def write_fixture_export(root, g, with_cfar=True):
+    """The files ICPWeightDataset reads, from the arrays of dataset_item.npz."""
+    map_seq, loc_seq = "boreas-map", "boreas-loc"
+    pdir = os.path.join(root, "vtr_export", "radar_lidar", map_seq, loc_seq)
+    os.makedirs(os.path.join(pdir, "scan"))
+    os.makedirs(os.path.join(pdir, "map"))
+    os.makedirs(os.path.join(root, "vtr_data", loc_seq, "radar"))
+    cdir = os.path.join(root, "cfar", loc_seq, "polar", "1.0_0.09")
+    os.makedirs(cdir)
+    np.savez(os.path.join(pdir, "index.npz"), loc_stamp=g["loc_stamp"], map_stamp=g["map_stamp"], T_gt=g["T_gt"],
+             T_map_sensor_robot=g["T_map_sensor_robot"])
+    for i, (ls, ms) in enumerate(zip(g["loc_stamp"], g["map_stamp"])):
+        g["raw_%d" % i].tofile(os.path.join(pdir, "scan", "%d_raw.bin" % ls))
+        g["filt_%d" % i].tofile(os.path.join(pdir, "scan", "%d_filt.bin" % ls))
+        g["map_%d" % i].tofile(os.path.join(pdir, "map", "%d.bin" % ms))
+        g["png_%d" % i].tofile(os.path.join(root, "vtr_data", loc_seq, "radar", "%d.png" % ls))
+        if with_cfar:
+            g["cfar_png_%d" % i].tofile(os.path.join(cdir, "%d.png" % ls))
+    return [[map_seq, loc_seq]]
+
+
+def dataset_params(**over):
+    p = {"map_sensor": "lidar", "loc_sensor": "radar", "random": False, "num_train": -1, "num_val": -1, "augment": False,
+         "float_type": torch.float32, "use_gt": False, "gt_eye": True, "pos_std": 2.0, "rot_std": 0.6, "a_thresh": 1.0,
+         "b_thresh": 0.09, "network_input_type": "polar", "max_loc_pts": 40, "max_map_pts": 80}
+    p.update(over)
+    return p
+
+
+def assert_same(a, b, path=""):
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), (path, a.keys(), b.keys())
+        for k in a:
+            assert_same(a[k], b[k], path + "/" + str(k))
+    elif torch.is_tensor(a):
+        assert a.dtype == b.dtype and torch.equal(a.cpu(), b.cpu()), path
+    else:
+        assert a == b, path

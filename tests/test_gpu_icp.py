@@ -392,3 +392,90 @@ def test_kat_trim_boundary_closed_form(r2, kept):
     want = kat.two_group_delta_y(r2, n1, n2, r1, None, 1.0, 5.0)
     assert abs(d[1] - want) <= 2e-7 * max(1.0, abs(want))
     assert (abs(want - r1) < 1e-7) == (not kept)
+
+
+@pytest.mark.parametrize("dim,icp_type", [(2, "pt2pl"), (3, "pt2pt")])
+def test_icp_stage_entries_equal_one_forward_iteration_and_flag_unarmed_keys(dim, icp_type):
+    """mmk_nn_search -> keys -> mmk_icp_accumulate -> mmk_icp_solve_update == one iteration of mmk_icp_forward (bit for bit:
+    same kernels), and a key that no search kernel wrote raises MMK_ICP_STATUS_UNARMED_KEY instead of passing as a
+    correspondence."""
+    import ctypes
+    from mm_masking_amd import _lib
+    import importlib
+    icp_mod = importlib.import_module("mm_masking_amd.dICP.ICP")       # the module (the package re-exports the class under the same name)
+    ICP = icp_mod.ICP
+    L = _lib.lib()
+    rng = np.random.default_rng(40 + dim)
+    B, N, M = 3, 700, 2100
+    tgt = rng.uniform(-40, 40, (B, M, 6)).astype(np.float32)
+    nrm = rng.normal(size=(B, M, 3))
+    if dim == 2:
+        nrm[..., 2] = 0
+    tgt[..., 3:] = (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(np.float32)
+    if dim == 2:
+        tgt[..., 2] = 0
+    src = (tgt[:, rng.permutation(M)[:N], :3] + rng.normal(0, 0.05, (B, N, 3))).astype(np.float32)
+    w = rng.uniform(0.1, 1, (B, N)).astype(np.float32)
+    T0 = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    T0[:, 0, 3] = 0.4
+    T0[:, 1, 3] = -0.3
+    s, t, wt, Tt = (torch.from_numpy(a).to(DEV) for a in (src, tgt, w, T0.reshape(B, 16)))
+    lf = {"name": "huber", "metric": 1.0}
+    icp = ICP(icp_type, differentiable=False, max_iterations=1, tolerance=0.0)
+    ICP.NN_SEARCH_OVERRIDE = None
+    ref = icp.icp(s, t, T_init=Tt.view(B, 4, 4), weight=wt, trim_dist=5.0, loss_fn=lf, dim=dim)["T"]
+    idx_ref = icp.last_state["idx"][0]
+    icp_mod.check_errors(wait=True)                                   # the clean call raised nothing
+
+    p = icp._params(B, N, M, 6, dim, lf, 5.0, save_state=False)
+    Mpad = L.mmk_nn_padded_m(M)
+    planar = torch.empty(B, dim, Mpad, dtype=torch.float32, device=DEV)
+    _lib.check(L.mmk_pack_target(_lib.ptr(t), B, M, 6, dim, _lib.ptr(planar), _lib.stream_ptr(DEV)))
+    ws = torch.empty(L.mmk_nn_workspace_bytes(B, N, M, dim), dtype=torch.uint8, device=DEV)
+    idx = torch.empty(B, N, dtype=torch.int32, device=DEV)
+    d2 = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    _lib.check(L.mmk_nn_search(_lib.ptr(s), _lib.ptr(planar), _lib.ptr(Tt), B, N, M, dim, _lib.ptr(idx), _lib.ptr(d2),
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV)))
+    keys = (d2.view(torch.int32).to(torch.int64) << 32) | idx.to(torch.int64)
+    n_part = L.mmk_icp_partials_count(ctypes.byref(p))
+    assert n_part == B * ((N + 255) // 256) * (9 if dim == 2 else 27)
+
+    def stage(keys_t):
+        parts = torch.zeros(n_part, dtype=torch.float64, device=DEV)
+        idx_out = torch.full((B, N), -7, dtype=torch.int32, device=DEV)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        _lib.check(L.mmk_icp_accumulate(ctypes.byref(p), _lib.ptr(s), _lib.ptr(t), _lib.ptr(wt), _lib.ptr(Tt), _lib.ptr(keys_t),
+                                        _lib.ptr(idx_out), _lib.ptr(parts), _lib.ptr(status), _lib.stream_ptr(DEV)))
+        T1 = torch.empty(B, 16, dtype=torch.float32, device=DEV)
+        delta = torch.empty(B, 6, dtype=torch.float64, device=DEV)
+        A = torch.empty(B, 36, dtype=torch.float64, device=DEV)
+        act_in = torch.ones(B, dtype=torch.int32, device=DEV)
+        act_out = torch.empty(B, dtype=torch.int32, device=DEV)
+        _lib.check(L.mmk_icp_solve_update(ctypes.byref(p), _lib.ptr(parts), _lib.ptr(Tt), _lib.ptr(T1), _lib.ptr(delta), _lib.ptr(A),
+                                          _lib.ptr(act_in), _lib.ptr(act_out), _lib.stream_ptr(DEV)))
+        torch.cuda.synchronize()
+        return idx_out, T1.view(B, 4, 4), int(status.item())
+
+    idx_out, T1, status = stage(keys)
+    assert status == 0
+    assert torch.equal(idx_out, idx_ref) and torch.equal(idx_out, idx)
+    assert torch.equal(T1, ref)
+    # one key nobody armed, one index outside the target: flagged, and clamped so that nothing is read out of bounds
+    bad = keys.clone()
+    bad[1, 5] = -1                                   # NN_KEY_INIT = ~0
+    bad[2, 9] = (bad[2, 9] & ~0xffffffff) | (M + 3)
+    idx_bad, _, status = stage(bad)
+    assert status == icp_mod.ICP_STATUS_UNARMED_KEY
+    assert int(idx_bad[1, 5]) == M - 1 and int(idx_bad[2, 9]) == M - 1
+    same = torch.ones(B, N, dtype=torch.bool, device=DEV)
+    same[1, 5] = same[2, 9] = False
+    assert torch.equal(idx_bad[same], idx_ref[same])
+    # the Python watch turns a raised flag into an error at the next check
+    slot = torch.zeros(1, dtype=torch.int32).pin_memory()
+    slot[0] = icp_mod.ICP_STATUS_UNARMED_KEY
+    ev = torch.cuda.Event()
+    ev.record()
+    icp_mod._status.pending.append((ev, slot))
+    with pytest.raises(_lib.MmkError, match="UNARMED_KEY"):
+        icp_mod.check_errors(wait=True)
+    icp_mod.check_errors(wait=True)                  # consumed: clean again

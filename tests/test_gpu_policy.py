@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from mm_masking_amd import synthetic
+from mm_masking_amd import _lib, synthetic
+from mm_masking_amd import radar_utils as ru
 from mm_masking_amd import train_icp_weights as trn
 from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
 
@@ -359,3 +360,15 @@ def test_fit_epoch_loop_and_resume(tmp_path):
     assert d == 0.0          # a resumed run repeats the uninterrupted run bit for bit (no float atomics in the step)
     # (the 50-iteration inference ICP amplifies the 1e-4 parameter differences on pairs it does not converge on)
     assert abs(h_res["best_norm"] - h_full["best_norm"]) < 0.05 * h_full["best_norm"]
+
+
+def test_device_guard_refuses_foreign_device():
+    """A tensor on another HIP device than the current one must not reach a kernel launch."""
+    if torch.cuda.device_count() < 2:
+        # one-GPU box: the guard itself, on a device index that is not the current one
+        with pytest.raises(_lib.MmkError, match="current HIP device"):
+            _lib.stream_ptr(torch.device("cuda", torch.cuda.current_device() + 1))
+        return
+    x = torch.zeros(1, 4, 400, device="cuda:1")
+    with pytest.raises(_lib.MmkError, match="current HIP device"):
+        ru.cfar_mask(x, 0.0596)

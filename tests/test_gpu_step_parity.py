@@ -73,3 +73,38 @@ def test_config2_dim3_full_step_parity():
     assert res["loss_rel_err"] < 1e-4, res
     assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
     assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
+
+
+def test_training_step_is_bit_reproducible():
+    """BASELINE configs[2] (B=32, N=5120, M=20480, 10 iterations, pt2pl Huber, dropout 0.05): the step run twice from the same
+    state gives the same loss, the same 46 gradients and the same updated parameters, bit for bit.  What made it differ
+    before round 3: float atomics in the first-layer weight gradient, the final layer's gradient and the mask-gradient
+    scatter of extract_weights (now block partials + ordered reductions / per-pixel chains summed in point order)."""
+    from mm_masking_amd import synthetic
+    from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+    B = 32
+    params = trn.default_params(DEV)
+    params.update({"icp_type": "pt2pl", "icp_loss_fn": {"name": "huber", "metric": 1.0}, "max_iter": 10, "dropout": 0.05})
+    raw = synthetic.make_batch(list(range(4000, 4000 + B)), device=DEV)
+    lw = trn.loss_weights_from(params)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(77)
+        model = LearnICPWeightPolicy(params).to(DEV)
+        model.train()
+        opt = trn.make_optimizer(model, params)
+        out = []
+        for step in range(2):                   # two steps: the second one starts from Adam-updated parameters
+            batch = trn.prepare_batch(raw, params, max_loc_pts=5120)
+            loss, _ = trn.train_step(model, batch, opt, lw, DEV)
+            out.append((loss.clone(), [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()]))
+        runs.append(out)
+    names = [n for n, _ in model.named_parameters()]
+    assert len(names) == 46
+    for step in range(2):
+        (l0, g0, p0), (l1, g1, p1) = runs[0][step], runs[1][step]
+        assert torch.equal(l0, l1), (step, float(l0), float(l1))
+        for n, a, b in zip(names, g0, g1):
+            assert torch.equal(a, b), ("gradient", step, n, float((a - b).abs().max()))
+        for n, a, b in zip(names, p0, p1):
+            assert torch.equal(a, b), ("parameter", step, n)

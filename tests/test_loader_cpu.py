@@ -1,10 +1,8 @@
-"""Round-3 CPU tests: the worker-safe loader.  ``ICPWeightDataset`` with
-``params["batched_prepare"]`` returns CPU-only items (uint8 polar rows, azimuths, clouds) that a
-``DataLoader(num_workers=4)`` can produce in parallel, as the reference does
-(/root/reference/mm_masking/train_icp_weights.py:454-455, icp_weight_dataset.py:323-362); ``finish_batch``
-turns a collated batch into the reference's batch dictionary.  Checked here on the polar network input
-(no HIP call) against the default item mode, which tests/test_round2_cpu.py pins to the reference's own
-``__getitem__`` output (tests/golden/dataset_item.npz)."""
+"""CPU-only checks of the real-data loader: ``ICPWeightDataset`` over a plain-file export against the
+dictionaries the reference's own ``__getitem__`` / ``load_graph_data`` returned (tests/golden/dataset_item.npz), the
+worker-safe item mode (``params["batched_prepare"]``: CPU-only items that a ``DataLoader(num_workers=4)`` produces in parallel as
+/root/reference/mm_masking/train_icp_weights.py:454-455 does, finished per batch by ``finish_batch``), the native batch fill
+(``mmk_host_read_rows{,_batch}``) and ``DeviceLoader`` on a CPU device."""
 import os
 
 import numpy as np
@@ -12,23 +10,53 @@ import torch
 
 from mm_masking_amd import icp_weight_dataset as ds
 
-from test_round2_cpu import _write_export, dataset_params
+from export_util import assert_same, dataset_params, write_fixture_export
 
 
-def _same(a, b, path=""):
-    if isinstance(a, dict):
-        assert a.keys() == b.keys(), (path, a.keys(), b.keys())
-        for k in a:
-            _same(a[k], b[k], path + "/" + str(k))
-    elif torch.is_tensor(a):
-        assert a.dtype == b.dtype and torch.equal(a, b), path
-    else:
-        assert a == b, path
+def test_dataset_item_matches_reference_polar(golden_dir, tmp_path):
+    """ICPWeightDataset.__getitem__ (polar network input, no augmentation: no HIP call) on the export written from
+    the fixture, against the dictionaries the reference's __getitem__ / load_graph_data returned."""
+    g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
+    pairs = write_fixture_export(str(tmp_path), g)
+    d = ds.ICPWeightDataset(pairs, dataset_params(), dataset_type="train", data_dir=str(tmp_path))
+    assert len(d) == 2 and d.target_pad_val == 1000.0 and d.augment is False
+    # T_init is exp of a seeded uniform draw (icp_weight_dataset.py:261-277): planar, inside the envelope
+    for T in d.T_loc_init:
+        assert abs(float(T[0, 3])) <= 2.0 and abs(float(T[1, 3])) <= 2.0 and float(T[2, 3]) == 0.0
+        assert abs(np.arctan2(float(T[1, 0]), float(T[0, 0]))) <= 0.6 + 1e-6
+    d.T_loc_init = torch.from_numpy(g["T_init"])             # the fixture's initial guesses
+    for i in range(2):
+        it = d[i]
+        pre = "p%d_" % i
+        for key, val in (("raw_pc", it["loc_data"]["raw_pc"]), ("filtered_pc", it["loc_data"]["filtered_pc"]),
+                         ("fft_sub", it["loc_data"]["fft_data"]), ("cfar_sub", it["loc_data"]["fft_cfar"]),
+                         ("map_pc", it["map_data"]["pc"]), ("T_init", it["transforms"]["T_ml_init"]),
+                         ("T_gt", it["transforms"]["T_ml_gt"])):
+            assert val.dtype == torch.float32
+            assert np.array_equal(val.numpy(), g[pre + key]), key
+        assert [it["loc_data"]["timestamp"], it["map_data"]["timestamp"]] == g[pre + "stamps"].tolist()
+        assert it["map_data"]["pc"].shape == (80, 6) and it["loc_data"]["raw_pc"].shape == (40, 3)
+    # a DataLoader batches the items into the Row-D dictionary of SURVEY.md §8a
+    batch = next(iter(torch.utils.data.DataLoader(d, batch_size=2, shuffle=False, num_workers=0)))
+    assert batch["loc_data"]["fft_data"].shape == (2, 40, 336) and batch["map_data"]["pc"].shape == (2, 80, 6)
+    assert batch["transforms"]["T_ml_init"].shape == (2, 4, 4)
+    # padding sizes derived from the data when params does not fix them
+    d2 = ds.ICPWeightDataset(pairs, dataset_params(max_loc_pts=0, max_map_pts=0, num_val=1), dataset_type="test",
+                             data_dir=str(tmp_path))
+    assert len(d2) == 1 and d2.max_loc_pts == 30 and 0 < d2.max_map_pts <= 90
+    assert d.get_item_from_loc_timestamp(int(g["loc_stamp"][1]))["loc_data"]["timestamp"] == int(g["loc_stamp"][1])
+
+
+def test_png_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (13, 29), dtype=np.uint8)
+    ds.write_png_gray(str(tmp_path / "a.png"), img)
+    assert np.array_equal(ds.read_png_gray(str(tmp_path / "a.png")), img)
 
 
 def test_worker_items_finish_to_the_reference_batch(golden_dir, tmp_path):
     g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
-    pairs = _write_export(str(tmp_path), g)
+    pairs = write_fixture_export(str(tmp_path), g)
     ref = ds.ICPWeightDataset(pairs, dataset_params(), dataset_type="train", data_dir=str(tmp_path))
     wrk = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
     wrk.T_loc_init = ref.T_loc_init.clone()
@@ -40,31 +68,31 @@ def test_worker_items_finish_to_the_reference_batch(golden_dir, tmp_path):
     for rep in range(2):
         got = next(iter(torch.utils.data.DataLoader(wrk, batch_size=2, shuffle=False, num_workers=4)))
         fin = ds.finish_batch(got, "cpu", network_input_type="polar")
-        _same(fin, want)
+        assert_same(fin, want)
         assert os.path.exists(wrk.loc_radar_path_list[0] + ".u8") and os.path.exists(wrk.loc_cfar_path_list[0] + ".u8")
-    # the items of the default mode equal the reference's own (test_round2_cpu.py); spot-check the chain here too
+    # the items of the default mode equal the reference's own (test_dataset_item_matches_reference_polar); spot-check the chain here too
     assert np.array_equal(fin["loc_data"]["fft_data"][0].numpy(), g["p0_fft_sub"])
     # a stale cache (older than its PNG) is ignored and rewritten
     cpath = wrk.loc_radar_path_list[1] + ".u8"
     with open(cpath, "wb") as f:
         f.write(b"\x00" * 16)
     os.utime(cpath, (1, 1))
-    _same(ds.finish_batch(torch.utils.data.default_collate([wrk[0], wrk[1]]), "cpu", network_input_type="polar"), want)
+    assert_same(ds.finish_batch(torch.utils.data.default_collate([wrk[0], wrk[1]]), "cpu", network_input_type="polar"), want)
     assert os.path.getsize(cpath) > 16
     # DeviceLoader on a CPU device: same batches, in order
     for mode in ("threads", "processes"):
         dl = ds.DeviceLoader(wrk, batch_size=1, device="cpu", num_workers=2, mode=mode)
         got = list(dl)
         assert len(got) == len(dl) == 2
-        _same(torch.utils.data.default_collate([ref[0]]), got[0])
-        _same(torch.utils.data.default_collate([ref[1]]), got[1])
-    _same(want, next(iter(ds.DeviceLoader(wrk, batch_size=2, device="cpu", num_workers=4))))
+        assert_same(torch.utils.data.default_collate([ref[0]]), got[0])
+        assert_same(torch.utils.data.default_collate([ref[1]]), got[1])
+    assert_same(want, next(iter(ds.DeviceLoader(wrk, batch_size=2, device="cpu", num_workers=4))))
 
 
 def test_worker_items_augmentation_matches_default_mode(golden_dir, tmp_path):
     """Same yaw draw -> same rolled rows, azimuths and rotated clouds in both item modes (icp_weight_dataset.py:425-452)."""
     g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
-    pairs = _write_export(str(tmp_path), g)
+    pairs = write_fixture_export(str(tmp_path), g)
     ref = ds.ICPWeightDataset(pairs, dataset_params(augment=True), dataset_type="train", data_dir=str(tmp_path))
     wrk = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train",
                               data_dir=str(tmp_path))
@@ -74,7 +102,7 @@ def test_worker_items_augmentation_matches_default_mode(golden_dir, tmp_path):
         a = ref[i]
         torch.manual_seed(77 + i)
         b = ds.finish_batch(torch.utils.data.default_collate([wrk[i]]), "cpu", network_input_type="polar")
-        _same(torch.utils.data.default_collate([a]), b)
+        assert_same(torch.utils.data.default_collate([a]), b)
 
 
 def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path):
@@ -82,7 +110,7 @@ def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path
     clouds from the prepared-cloud cache) + ``finish_batch`` (rotation of the clouds on the device) against the default
     item mode under the same yaw draw: images, azimuths, poses, stamps bit-equal; rotated clouds to fp32 rounding."""
     g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
-    pairs = _write_export(str(tmp_path), g)
+    pairs = write_fixture_export(str(tmp_path), g)
     ref = ds.ICPWeightDataset(pairs, dataset_params(augment=True), dataset_type="train", data_dir=str(tmp_path))
     wrk = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train",
                               data_dir=str(tmp_path))
@@ -97,9 +125,9 @@ def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path
             wrk.fill_batch([i], bufs, threads=2)
             b = ds.finish_batch(bufs, "cpu", network_input_type="polar")
             for key in ("fft_data", "fft_cfar", "timestamp"):
-                _same(a["loc_data"][key], b["loc_data"][key], key)
-            _same(a["transforms"], b["transforms"])
-            _same(a["map_data"]["timestamp"], b["map_data"]["timestamp"])
+                assert_same(a["loc_data"][key], b["loc_data"][key], key)
+            assert_same(a["transforms"], b["transforms"])
+            assert_same(a["map_data"]["timestamp"], b["map_data"]["timestamp"])
             for x, y in ((a["loc_data"]["raw_pc"], b["loc_data"]["raw_pc"]), (a["loc_data"]["filtered_pc"], b["loc_data"]["filtered_pc"]),
                          (a["map_data"]["pc"], b["map_data"]["pc"])):
                 assert x.shape == y.shape
@@ -110,7 +138,7 @@ def test_native_fill_matches_default_mode_with_augmentation(golden_dir, tmp_path
     wrk0 = ds.ICPWeightDataset(pairs, dataset_params(batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
     wrk0.T_loc_init = ref0.T_loc_init.clone()
     got = next(iter(ds.DeviceLoader(wrk0, batch_size=2, device="cpu", num_workers=3)))
-    _same(torch.utils.data.default_collate([ref0[0], ref0[1]]), got)
+    assert_same(torch.utils.data.default_collate([ref0[0], ref0[1]]), got)
     # the prepared-cloud cache is keyed on everything the clouds depend on: another padding value (or re-exported cloud files)
     # gets clouds of its own instead of the stale file
     n_before = len(os.listdir(os.path.join(wrk0.pair_dirs[0], "prepared")))
@@ -132,7 +160,7 @@ def test_device_loader_draws_from_its_own_generator(golden_dir, tmp_path):
     """Shuffle order and augmentation yaws come from the loader's private generator: the same seed gives the same batches
     whatever is drawn from the global generator in between (the training thread draws from it concurrently)."""
     g = np.load(os.path.join(golden_dir, "dataset_item.npz"), allow_pickle=False)
-    pairs = _write_export(str(tmp_path), g)
+    pairs = write_fixture_export(str(tmp_path), g)
     dset = ds.ICPWeightDataset(pairs, dataset_params(augment=True, batched_prepare=True), dataset_type="train", data_dir=str(tmp_path))
 
     def run(noise):
@@ -147,7 +175,7 @@ def test_device_loader_draws_from_its_own_generator(golden_dir, tmp_path):
     torch.manual_seed(2)
     b = run(True)
     for x, y in zip(a, b):
-        _same(x, y)
+        assert_same(x, y)
 
 
 def test_host_read_rows_roll_and_columns(tmp_path):
@@ -180,62 +208,3 @@ def test_host_read_rows_roll_and_columns(tmp_path):
         assert np.array_equal(o, np.roll(img[:, k:k + 10], k - 4, axis=0)), k
     jobs[5].rows = 9
     assert L.mmk_host_read_rows_batch(jobs, 12, 3) != 0 and b"1 of 12 jobs failed" in L.mmk_last_error()
-
-
-def _device_code_objects(so_path):
-    """The gfx950 code objects embedded in the library: every clang offload bundle of its .hip_fatbin section."""
-    import struct
-    import subprocess
-    import tempfile
-    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
-    with tempfile.TemporaryDirectory() as td:
-        fat = os.path.join(td, "fat.bin")
-        subprocess.check_call([objcopy, "--dump-section", ".hip_fatbin=" + fat, so_path, os.path.join(td, "copy.so")])
-        blob = open(fat, "rb").read()
-    magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    out = []
-    pos = blob.find(magic)
-    while pos >= 0:
-        n, = struct.unpack_from("<Q", blob, pos + len(magic))
-        q = pos + len(magic) + 8
-        for _ in range(n):
-            off, size, tl = struct.unpack_from("<QQQ", blob, q)
-            triple = blob[q + 24:q + 24 + tl].decode()
-            q += 24 + tl
-            if "gfx950" in triple:
-                out.append(blob[pos + off:pos + off + size])
-        pos = blob.find(magic, pos + 1)
-    return out
-
-
-def test_no_kernel_uses_scratch_memory(tmp_path):
-    """Every kernel of the library keeps its per-lane state in registers (or LDS): private_segment_fixed_size == 0 in each
-    kernel's metadata.  A 48-byte scratch array in the matrix-core NN kernel (coordinates read back at a run-time offset) made
-    correspondences change from run to run on the MI355X: arrays indexed at run time belong in LDS."""
-    import re
-    import subprocess
-    from mm_masking_amd import _lib
-    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
-    if not os.path.exists(readelf):
-        import pytest
-        pytest.skip("llvm-readelf not available")
-    objs = _device_code_objects(_lib.build())
-    assert len(objs) >= 4                              # icp, radar, unet, loader (sources without kernels embed none)
-    kernels = 0
-    for k, elf in enumerate(objs):
-        path = tmp_path / ("dev%d.elf" % k)
-        path.write_bytes(elf)
-        notes = subprocess.check_output([readelf, "--notes", str(path)], text=True)
-        names = re.findall(r"^\s+\.name:\s+(\S+)\s*$", notes, flags=re.M)
-        sizes = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)
-        kernel_names = [n for n in names if n.startswith("_Z")]
-        assert len(sizes) == len(kernel_names) and sizes, (len(sizes), len(kernel_names))
-        kernels += len(sizes)
-        bad = [(n, s) for n, s in zip(kernel_names, sizes) if int(s) != 0]
-        assert not bad, "kernels with scratch memory: %r" % bad
-        # no kernel may ask for a run-time sized stack either (round 4: the failing round-3 code object had a fixed 48-byte
-        # segment and .uses_dynamic_stack false -- the descriptor was not the cause -- but a dynamic stack would defeat the
-        # size check above, so it is asserted too)
-        dyn = re.findall(r"\.uses_dynamic_stack:\s+(\S+)", notes)
-        assert len(dyn) == len(kernel_names) and all(d == "false" for d in dyn), dyn
-    assert kernels >= 60
