@@ -35,7 +35,8 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("MMK_BENCH_MAX_CORES", "16"))))
 
 
-# must be set before torch / libgomp start their thread pools
+# must be set before torch / libgomp start their thread pools (a value the user exported is kept, and handed on to the ranks)
+_USER_OMP = os.environ.get("OMP_NUM_THREADS")
 os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
 
 import numpy as np
@@ -99,7 +100,8 @@ def launch_ranks(argv, n, runner=None):
             port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    # each of the n ranks gets its share of the host cores (this process's own default above is the whole host)
+    env["OMP_NUM_THREADS"] = _USER_OMP if _USER_OMP is not None else str(max(1, usable_cores() // n))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = launcher_command(argv, n, port)
@@ -365,9 +367,15 @@ def main():
     ap.add_argument("--no-grid", action="store_true", help="skip the side measurement of the exact grid NN engine")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (sparse scenes, dim 3, inference)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N-rank code path whatever N is: a process group is initialised (RCCL for --gpus 1 too), the gradient "
+                         "all-reduce(s) and the global min-max all-reduce are issued, the line carries the `ddp` block")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="ONE gradient all-reduce between backward and step instead of the three bucket all-reduces that overlap "
+                         "the backward pass (mm_masking_amd/ddp.py)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -379,7 +387,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP kernels with no CPU fallback")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" = RCCL over xGMI; MMK_BENCH_BACKEND=gloo only for rehearsing the rank logic on a 1-GPU box
         backend = os.environ.get("MMK_BENCH_BACKEND", "nccl")
@@ -409,7 +418,12 @@ def main():
     model = LearnICPWeightPolicy(params).to(device)
     model.train()
     opt = trn.make_optimizer(model, params)
-    sync = ddp.FlatGradSync(model) if world > 1 else None
+    if args.force_dist:
+        params["global_minmax"] = True          # the 2C-float MAX all-reduce in front of the first layer, as in an N-rank job
+        model.global_minmax = True
+        from mm_masking_amd import unet_hip
+        unet_hip.FORCE_COLLECTIVES = True
+    sync = ddp.FlatGradSync(model, overlap=not args.no_overlap, force_collective=args.force_dist) if dist_on else None
     if sync is not None:
         sync.sync_params(0)
 
@@ -427,7 +441,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -439,7 +453,7 @@ def main():
         best, streak = float("inf"), 0
         # (with more than one rank every step holds a collective: all ranks must run the same number of
         # steps, so the count is fixed there instead of adaptive)
-        n_settle = args.settle if world == 1 else min(args.settle, 25)
+        n_settle = args.settle if not dist_on else min(args.settle, 25)
         for i in range(n_settle):
             t_s = time.perf_counter()
             one_step(i)
@@ -447,7 +461,7 @@ def main():
             d_s = time.perf_counter() - t_s
             best = min(best, d_s)
             streak = streak + 1 if d_s <= 1.10 * best else 0
-            if world == 1 and i >= 5 and streak >= 5:
+            if not dist_on and i >= 5 and streak >= 5:
                 break
     progress("warm-up: %d steps" % args.warmup)
     for i in range(args.warmup):
@@ -460,7 +474,7 @@ def main():
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))
     if sync is not None:
-        sync.timing, sync.calls = [], 0
+        sync.timing, sync.exposed, sync.calls = [], [], 0
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
@@ -485,26 +499,32 @@ def main():
     _lib.check(L.mmk_nn_profile_end(ms, cap, ctypes.byref(n_rec)))
     nn_ms = np.array(ms[:min(n_rec.value, cap)], dtype=np.float64)
     ddp_block = None
-    if world > 1:
+    if dist_on:
         # what the process group saw, from the group itself: every rank contributes its own wall time and the mean
         # duration of its gradient all-reduces (events on the stream the collective is ordered on)
         ar_ms = [a.elapsed_time(b) for a, b in (sync.timing or [])]
-        sync.timing = None
-        mine = torch.tensor([dt, float(np.mean(ar_ms)) if ar_ms else float("nan"), float(np.max(ar_ms)) if ar_ms else float("nan")],
-                            dtype=torch.float64, device=device)
+        ex_ms = [a.elapsed_time(b) for a, b in (sync.exposed or [])]
+        sync.timing = sync.exposed = None
+        per_step = sync.calls / float(args.steps)
+        mine = torch.tensor([dt, float(np.sum(ar_ms)) / args.steps if ar_ms else float("nan"), float(np.max(ar_ms)) if ar_ms else float("nan"),
+                             float(np.mean(ex_ms)) if ex_ms else float("nan")], dtype=torch.float64, device=device)
         everyone = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(everyone, mine)
         rows = torch.stack(everyone).cpu().numpy()
         dt = float(rows[:, 0].max())                # MAX over ranks, as the contract says
         ddp_block = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "rank_count_reporting": int(len(rows)),
-                     "allreduce_bytes": sync.allreduce_bytes(), "allreduce_calls_per_step": sync.calls / float(args.steps),
+                     "allreduce_bytes": sync.allreduce_bytes(), "allreduce_calls_per_step": per_step,
+                     "overlap": bool(sync.overlap), "bucket_elements": [hi - lo for lo, hi in (sync.buckets_last or [])],
                      "allreduce_ms": float(np.nanmean(rows[:, 1])), "allreduce_ms_max_over_ranks_and_steps": float(np.nanmax(rows[:, 2])),
+                     "allreduce_exposed_ms": None if np.isnan(rows[:, 3]).all() else float(np.nanmean(rows[:, 3])),
                      "ms_per_step_min_over_ranks": float(rows[:, 0].min()) / args.steps * 1e3,
                      "ms_per_step_max_over_ranks": float(rows[:, 0].max()) / args.steps * 1e3,
                      "devices_visible": torch.cuda.device_count(), "global_minmax": bool(getattr(model, "global_minmax", False)),
-                     "note": "one flat fp32 sum all-reduce of the U-Net backward's own gradient block per step (mm_masking_amd/ddp.py); "
-                             "allreduce_ms = mean over ranks of the mean event time around the collective, which includes waiting for "
-                             "the slowest rank to arrive"}
+                     "note": "fp32 sum all-reduce of the U-Net backward's own gradient block (mm_masking_amd/ddp.py): with overlap in the three "
+                             "buckets in which the backward completes it (decoder + final layer, encoder blocks 3-5, encoder blocks 0-2), each "
+                             "on a communication stream behind its own completion event; allreduce_ms = per-step sum of the event times "
+                             "around the collectives (mean over ranks; it includes waiting for the slowest rank), allreduce_exposed_ms = time "
+                             "the step's own stream waits for the communication stream before the optimizer (what the overlap leaves)"}
 
     # host cost of enqueueing one step, measured with an EMPTY launch queue (synchronise, time the Python call, synchronise):
     # inside the timed loop the host runs ahead until the queue is full and then waits for the GPU, so the loop's host
@@ -628,7 +648,7 @@ def main():
                 result["cpu_baseline"]["pose_parity"] = pose_parity(model, params, device)
         print(json.dumps(result))
         sys.stdout.flush()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

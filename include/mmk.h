@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMK_VERSION 402 /* 0.4.2: arg-max codes of the poolings (mmk_conv_desc.pool_arg, mmk_maxpool2_fwd_arg / _bwd_arg, mmk_unet_desc.keep_full_res); 0.4.1: mmk_pose_loss_*, mmk_bce_mean_*; 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
+#define MMK_VERSION 500 /* 0.5.0: mmk_unet_backward_buckets / mmk_unet_grad_bucket (per-bucket completion events for an overlapped gradient all-reduce); 0.4.2: arg-max codes of the poolings (mmk_conv_desc.pool_arg, mmk_maxpool2_fwd_arg / _bwd_arg, mmk_unet_desc.keep_full_res); 0.4.1: mmk_pose_loss_*, mmk_bce_mean_*; 0.4.0: mmk_icp_status / _accumulate / _solve_update; 0.3.1: mmk_host_read_rows_batch; 0.3.0: no float atomics left (first / final layer gradients and the mask-gradient scatter take workspaces; mmk_conv3x3_wgrad + _unpack removed) */
 
 #define MMK_OK 0
 #define MMK_ERR_ARG (-1)
@@ -464,6 +464,17 @@ int mmk_unet_forward(const mmk_unet_desc *d, void *stream);
  * overwritten with dL/dparam. */
 int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch,
                       size_t scratch_bytes, void *stream);
+/* Data-parallel form of mmk_unet_backward (nothing upstream to mirror: the reference has no multi-GPU path; BASELINE.json
+ * configs[3] asks for the gradient all-reduce to overlap the backward pass).  The parameter gradients of a pass become final
+ * in MMK_UNET_GRAD_BUCKETS groups; mmk_unet_grad_bucket tells which contiguous run of the 46 parameters (state_dict order)
+ * group `bucket` holds -- 0: decoder + final layer (24..45), 1: encoder blocks 3-5 (12..23), 2: encoder blocks 0-2 (0..11),
+ * the order in which they complete.  bucket_events: HOST array of MMK_UNET_GRAD_BUCKETS hipEvent_t the caller created;
+ * event b is recorded behind the last kernel that writes a gradient of group b, so another stream that waits for it may
+ * read (all-reduce) that group while the rest of the pass is still running.  Results are those of mmk_unet_backward. */
+#define MMK_UNET_GRAD_BUCKETS 3
+int32_t mmk_unet_grad_bucket(int32_t bucket, int32_t *first_param, int32_t *n_params);
+int mmk_unet_backward_buckets(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch,
+                              size_t scratch_bytes, void *const *bucket_events, void *stream);
 /* Where an activation lives inside the workspace (tests / diagnostics): id 0..5 first conv output of encoder
  * block i, 6..11 second (post-dropout) output, 12..17 t[i] (block output after pooling), 18 + 5 j + {0..4}:
  * decoder block j's up-sampled input, a1, d1, a2, d2.  NHWC bf16 (B,h,w,c) at byte `offset`. */

@@ -83,7 +83,8 @@ def build(verbose=False):
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SOURCES]
     common = [os.path.join(csrc, "mmk_common.h"), os.path.join(csrc, "mmk_unet_shared.h"), os.path.join(_ROOT, "include", "mmk.h")]
-    extra = {"mmk_unet.hip": [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".inc")]}
+    incs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".inc")]
+    extra = {"mmk_unet.hip": incs, "mmk_loader.hip": incs}
     objdir = os.path.join(csrc, "_obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -178,6 +179,9 @@ def _declare(lib):
         "mmk_unet_scratch_bytes": (sz, [i32, i32, i32, i32]),
         "mmk_unet_forward": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp]),
         "mmk_unet_backward": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp, ctypes.POINTER(ctypes.c_void_p), c_vp, sz, c_vp]),
+        "mmk_unet_backward_buckets": (ctypes.c_int, [ctypes.POINTER(UNetDesc), c_vp, ctypes.POINTER(ctypes.c_void_p), c_vp, sz,
+                                                     ctypes.POINTER(ctypes.c_void_p), c_vp]),
+        "mmk_unet_grad_bucket": (i32, [i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
         "mmk_unet_tensor": (ctypes.c_int, [i32, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                            ctypes.POINTER(i32)]),
         "mmk_cfar_mask": (ctypes.c_int, [c_vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, f32, c_vp, c_vp]),

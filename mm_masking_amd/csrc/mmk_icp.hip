@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
         // run; a NaN coordinate finds nothing, so keys that nobody armed).  The round trip is sound in isolation
         // (scripts/ubench/scratch_roundtrip.hip) and so is the code object; what failed in the full
         // process is not established.  The library uses no scratch memory anywhere:
-        // tests/test_round3_cpu.py::test_no_kernel_uses_scratch_memory.
+        // tests/test_code_objects.py::test_no_kernel_uses_scratch_memory.
         float px[NNM_GROUPS], py[NNM_GROUPS], pz[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];
         int jseed[NNM_GROUPS];
         nn_bf16x8 bfr[KS][NNM_GROUPS];

@@ -372,8 +372,41 @@ extern "C" int mmk_unet_forward(const mmk_unet_desc *d, void *stream)
     return MMK_OK;
 }
 
+namespace {
+int unet_backward_impl(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch, size_t scratch_bytes,
+                       void *const *bucket_events, void *stream);
+}
+
 extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch,
                                  size_t scratch_bytes, void *stream)
+{
+    return unet_backward_impl(d, gmask, grads, scratch, scratch_bytes, nullptr, stream);
+}
+
+// The gradients of a pass become final in three groups, in this order (the order of the weight-gradient reductions below):
+// bucket 0 = decoder + final layer (parameters 24..45), bucket 1 = encoder blocks 3-5 (12..23), bucket 2 = encoder blocks 0-2
+// (0..11).  A data-parallel caller hands over one event per bucket and all-reduces a bucket on another stream as soon as its
+// event has fired, beside the rest of the backward pass (BASELINE.json configs[3]: "grad all-reduce overlapped ...").
+extern "C" int32_t mmk_unet_grad_bucket(int32_t bucket, int32_t *first_param, int32_t *n_params)
+{
+    static const int32_t first[MMK_UNET_GRAD_BUCKETS] = {24, 12, 0}, count[MMK_UNET_GRAD_BUCKETS] = {22, 12, 12};
+    MMK_REQUIRE(bucket >= 0 && bucket < MMK_UNET_GRAD_BUCKETS && first_param && n_params, "mmk_unet_grad_bucket: bad bucket %d", bucket);
+    *first_param = first[bucket];
+    *n_params = count[bucket];
+    return MMK_OK;
+}
+
+extern "C" int mmk_unet_backward_buckets(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch,
+                                         size_t scratch_bytes, void *const *bucket_events, void *stream)
+{
+    MMK_REQUIRE(bucket_events != nullptr, "mmk_unet_backward_buckets: NULL event array");
+    for (int b = 0; b < MMK_UNET_GRAD_BUCKETS; ++b) MMK_REQUIRE(bucket_events[b] != nullptr, "mmk_unet_backward_buckets: NULL event %d", b);
+    return unet_backward_impl(d, gmask, grads, scratch, scratch_bytes, bucket_events, stream);
+}
+
+namespace {
+int unet_backward_impl(const mmk_unet_desc *d, const float *gmask, float *const *grads, void *scratch, size_t scratch_bytes,
+                       void *const *bucket_events, void *stream)
 {
     MMK_REQUIRE(d != nullptr, "mmk_unet_backward: NULL descriptor");
     MMK_REQUIRE(d->x && d->params && d->workspace && d->mask && gmask && grads && scratch, "mmk_unet_backward: NULL pointer");
@@ -528,6 +561,8 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
     // the decoder's weight gradients are all enqueued: their slices are reduced under the >= 64-channel encoder levels, which
     // leave the HBM idle
     MMK_TRY(unpack(12, 21));
+    // (the final layer's gradients were written on the caller's stream before the fork the reduction waited for)
+    if (bucket_events) MMK_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_events[0], (hipStream_t)wstream));
     // ---- encoder, i = 5..1 (g_t = gradient w.r.t. t[i])
     const void *g_t = gz;
     for (int i = 5; i >= 1; --i) {
@@ -564,7 +599,10 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         // the >= 64-channel encoder layers have their weight gradients enqueued: reduce their slices now (the reduction reads
         // every partial slice; as one launch at the end it is the tail of the backward pass, and beside the 640 x 640 kernels
         // it competes for their HBM bandwidth)
-        if (i == 3) MMK_TRY(unpack(6, 11));
+        if (i == 3) {
+            MMK_TRY(unpack(6, 11));
+            if (bucket_events) MMK_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_events[1], (hipStream_t)wstream));
+        }
     }
     // ---- encoder block 0
     if (can_fuse(1, 8, p.H, p.W)) {
@@ -585,5 +623,7 @@ extern "C" int mmk_unet_backward(const mmk_unet_desc *d, const float *gmask, flo
         MMK_CHECK_HIP(hipEventRecord(ss->join, ss->st));
         MMK_CHECK_HIP(hipStreamWaitEvent(st, ss->join, 0));
     }
+    if (bucket_events) MMK_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_events[2], st));
     return MMK_OK;
 }
+}  // namespace

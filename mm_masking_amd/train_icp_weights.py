@@ -261,7 +261,17 @@ def train_policy(model, iterator, opt, loss_weights=[], device="cpu", epoch=None
         n += 1
     mean_loss = loss_hist / n
     mean_loss_comp = {k: sum(d[k] for d in loss_comp_hist) / len(loss_comp_hist) for k in loss_comp_hist[0]}
+    _check_device_errors(device)
     return mean_loss, mean_loss_comp
+
+
+def _check_device_errors(device):
+    """The ICP kernels report internal errors through a status word that is examined without synchronising the step (at the next
+    ICP call: dICP/ICP.py).  At the end of a pass nothing follows, so wait for the calls in flight and raise here: a flagged
+    call's poses must not reach a checkpoint or a reported metric unnoticed (one synchronisation per epoch)."""
+    if torch.device(device).type == "cuda":
+        from .dICP import ICP as icp_mod
+        icp_mod.check_errors(wait=True)
 
 
 def validate_policy(model, iterator, gt_eye=True, device="cpu", binary=False, neptune_run=None, epoch=None):
@@ -282,6 +292,7 @@ def validate_policy(model, iterator, gt_eye=True, device="cpu", binary=False, ne
             mean_w += model.mean_w
             val_acc += eval_validation_loss(T_pred, batch_T_gt, gt_eye=gt_eye)
             n += 1
+    _check_device_errors(device)
     return val_acc / n, mean_num_pc / n, mean_w / n, max_w, min_w
 
 
@@ -318,6 +329,7 @@ def generate_baseline(model, iterator, baseline_type="train", device="cpu",
                 lo = eval_validation_loss(T_pred_ones, batch_T_gt, gt_eye=gt_eye)[0]
             loss_init_hist.append(float(li))
             loss_ones_hist.append(float(lo))
+    _check_device_errors(device)
     return sum(loss_init_hist) / len(loss_init_hist), sum(loss_ones_hist) / len(loss_ones_hist)
 
 
@@ -377,8 +389,8 @@ def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_
                                                    loss_weights=lw, gt_eye=params["gt_eye"])
         hist["val_baseline"] = generate_baseline(policy, validation_iterator, baseline_type="val", device=dev,
                                                  binary=params["binary_inference"], gt_eye=params["gt_eye"])
-        avg_norm = validate_policy(policy, validation_iterator, device=dev, binary=params["binary_inference"],
-                                   gt_eye=params["gt_eye"], epoch=-1)[0]
+        avg_norm = _rank_mean(validate_policy(policy, validation_iterator, device=dev, binary=params["binary_inference"],
+                                              gt_eye=params["gt_eye"], epoch=-1)[0])
         best_norm = float(avg_norm[0, 0])
         log("Norm before training: %.6f" % best_norm)
     for epoch in range(start_epoch, params["num_epochs"]):
@@ -389,8 +401,8 @@ def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_
         mean_loss = float(mean_loss)
         t_train = time.time() - tic
         tic = time.time()
-        avg_norm = validate_policy(policy, validation_iterator, epoch=epoch, device=dev, binary=params["binary_inference"],
-                                   gt_eye=params["gt_eye"])[0]
+        avg_norm = _rank_mean(validate_policy(policy, validation_iterator, epoch=epoch, device=dev, binary=params["binary_inference"],
+                                              gt_eye=params["gt_eye"])[0])
         t_val = time.time() - tic
         total = float(avg_norm[0, 0])
         if total < best_norm or epoch == 0:
@@ -426,9 +438,21 @@ def fit(policy, training_iterator, validation_iterator, opt, params, checkpoint_
             src = _main_rank(is_main, dev)
             for t in policy.state_dict().values():
                 dist.broadcast(t, src=src)
-        hist["final_acc"] = [float(v) for v in validate_policy(policy, validation_iterator, device=dev,
-                                                              binary=params["binary_inference"], gt_eye=params["gt_eye"])[0][0]]
+        hist["final_acc"] = [float(v) for v in _rank_mean(validate_policy(policy, validation_iterator, device=dev,
+                                                                         binary=params["binary_inference"], gt_eye=params["gt_eye"])[0])[0]]
     return hist
+
+
+def _rank_mean(t):
+    """Mean over the ranks of a data-parallel job (identity in a single process): each rank validates its own shard of the
+    validation set, and the reference selects its best policy on the WHOLE set (train_icp_weights.py:534-537) -- with equal
+    shard sizes the mean of the shard means.  Every rank then takes the same best-policy decisions."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t / dist.get_world_size()
 
 
 def _main_rank(is_main, dev):

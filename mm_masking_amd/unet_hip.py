@@ -233,6 +233,9 @@ def conv_first(x, w, b, pre=None, slope=0.0):
     return y
 
 
+FORCE_COLLECTIVES = False     # one-rank rehearsal of the N-rank path (bench.py --force-dist): issue the collective at world size 1 too
+
+
 def channel_minmax(x, process_group=None, global_reduce=False):
     """(min, 1 / (max - min)) per channel of fp32 (B,C,H,W) over (B,H,W) -> (C,2) fp32: the offset and
     reciprocal scale of the policy's min-max normalisation (icp_weight_policy.py:151-155).
@@ -243,7 +246,7 @@ def channel_minmax(x, process_group=None, global_reduce=False):
     part = torch.empty(C * 2048, dtype=torch.float32, device=x.device)
     pre = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     import torch.distributed as dist
-    reduce = global_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+    reduce = global_reduce and dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or FORCE_COLLECTIVES)
     mm = torch.empty(C, 2, dtype=torch.float32, device=x.device) if reduce else None
     _lib.check(_lib.lib().mmk_channel_minmax(_p(x), B, C, H * W, _p(part), _p(pre), _p(mm), _sp(x.device)))
     if reduce:
@@ -552,6 +555,11 @@ class _UNet(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- the network as two C-ABI calls
+GRAD_BUCKET_EVENTS = None    # ddp.FlatGradSync(overlap=True) arms this with MMK_UNET_GRAD_BUCKETS recorded torch.cuda.Event objects: the
+#                              native backward then records event b behind the last kernel that writes a gradient of bucket b
+GRAD_BUCKET_PASSES = [0]     # backward passes that recorded the armed events (a pass that did not -- another driver, the BatchNorm
+#                              network -- must not be mistaken for one: stale events have long fired)
+GRAD_BUCKETS = ((24, 22), (12, 12), (0, 12))    # (first parameter, count) per bucket, in completion order (mmk_unet_grad_bucket)
 DRIVER = os.environ.get("MMK_UNET_DRIVER", "native")     # "native": mmk_unet_forward / _backward (csrc/mmk_unet_driver.hip);
 #                                                          "python": the launch-by-launch schedule of _UNet above (the same
 #                                                          kernels in the same order: bit-identical results; tests, diagnostics)
@@ -621,7 +629,14 @@ class _UNetNative(torch.autograd.Function):
         d = _lib.UNetDesc(B=B, H=H, W=W, cin=cin, x=x.data_ptr(), pre=None if ctx.pre is None else ctx.pre.data_ptr(), params=pp,
                           drop_p=p_drop, seed=seed, leaky_slope=slope, norm=norm, workspace=ws.data_ptr(),
                           workspace_bytes=ws.numel(), mask=ctx.mask.data_ptr())
-        _lib.check(L.mmk_unet_backward(ctypes.byref(d), _p(gmask), gp, _p(scratch), nscratch, _sp(dev)))
+        evs = GRAD_BUCKET_EVENTS
+        if evs is not None:
+            # data-parallel step: event b fires when the gradients of bucket b are final (include/mmk.h: mmk_unet_backward_buckets)
+            ep = (ctypes.c_void_p * len(evs))(*[ctypes.c_void_p(int(e.cuda_event)) for e in evs])
+            _lib.check(L.mmk_unet_backward_buckets(ctypes.byref(d), _p(gmask), gp, _p(scratch), nscratch, ep, _sp(dev)))
+            GRAD_BUCKET_PASSES[0] += 1
+        else:
+            _lib.check(L.mmk_unet_backward(ctypes.byref(d), _p(gmask), gp, _p(scratch), nscratch, _sp(dev)))
         ctx.ws = None
         return (None, None, None, None, None, None, None) + tuple(grads)
 

@@ -88,8 +88,13 @@ class TrainStepRef:
     """One reference-shaped training step on the CPU (the ``port`` baseline)."""
 
     def __init__(self, icp_type="pt2pl", loss_fn=None, max_iter=10, dim=2, dropout=0.05, seed=1234, lr=1e-4,
-                 loss_weights=None):
-        self.sd = {k: v.requires_grad_(True) for k, v in unet_ref.init_state_dict(1, seed).items()}
+                 loss_weights=None, state_dict=None, norm_weights=True):
+        """``state_dict``: start from these parameters (copied) instead of the seeded Xavier initialisation;
+        ``norm_weights``: params["norm_weights"] of the reference (icp_weight_policy.py:192-193)."""
+        init = unet_ref.init_state_dict(1, seed) if state_dict is None else \
+            {k: v.detach().to("cpu", torch.float32).clone() for k, v in state_dict.items()}
+        self.sd = {k: v.requires_grad_(True) for k, v in init.items()}
+        self.norm_weights = norm_weights
         self.opt = torch.optim.Adam(list(self.sd.values()), lr=lr)
         self.icp = dicp_ref.ICPRef(icp_type, differentiable=True, max_iterations=max_iter, tolerance=1e-5)
         self.loss_fn = loss_fn or {"name": "huber", "metric": 1.0}
@@ -99,7 +104,7 @@ class TrainStepRef:
 
     def forward(self, batch, training=True):
         x = unet_ref.assemble_input(batch["fft_data"])
-        mask = unet_ref.unet_mask(x, self.sd, dropout_p=self.dropout, training=training)
+        mask = unet_ref.unet_mask(x, self.sd, norm_weights=self.norm_weights, dropout_p=self.dropout, training=training)
         w = gather_weights(mask, batch["raw_pc"])
         out = self.icp.icp(batch["filtered_pc"], batch["map_pc"], T_init=batch["T_init"], weight=w,
                            trim_dist=5.0, loss_fn=self.loss_fn, dim=self.dim)

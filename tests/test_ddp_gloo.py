@@ -124,18 +124,22 @@ def _policy_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mm_masking_amd import train_icp_weights as trn
-        model, p = _policy(seed=10 + rank)        # different init per rank on purpose: rank 0's is broadcast
-        assert model.global_minmax                # the default inside a multi-rank job
-        model.train()
-        sync = ddp.FlatGradSync(model)
-        sync.sync_params(0)
-        opt = trn.make_optimizer(model, p)
-        losses = []
-        for step in range(2):
-            losses.append(_policy_step(model, opt, ddp.shard_indices(4, rank, world, start=4 * step), sync))
-        lt = torch.tensor(losses, dtype=torch.float64)
-        dist.all_reduce(lt)
-        out[rank] = (torch.cat([q.detach().flatten() for q in model.parameters()]), (lt / world).tolist())
+        res = {}
+        for overlap in (False, True):             # one all-reduce of the block / the three buckets of the native backward
+            model, p = _policy(seed=10 + rank)    # different init per rank on purpose: rank 0's is broadcast
+            assert model.global_minmax            # the default inside a multi-rank job
+            model.train()
+            sync = ddp.FlatGradSync(model, overlap=overlap)
+            sync.sync_params(0)
+            opt = trn.make_optimizer(model, p)
+            losses = []
+            for step in range(2):
+                losses.append(_policy_step(model, opt, ddp.shard_indices(4, rank, world, start=4 * step), sync))
+            lt = torch.tensor(losses, dtype=torch.float64)
+            dist.all_reduce(lt)
+            res[overlap] = (torch.cat([q.detach().flatten() for q in model.parameters()]), (lt / world).tolist(), sync.calls,
+                            sync.buckets_last)
+        out[rank] = res
     finally:
         dist.destroy_process_group()
 
@@ -150,7 +154,18 @@ def test_policy_host_logic_two_ranks_equal_one_process():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_policy_worker, args=(world, port, out), nprocs=world, join=True)
+    both = out[0], out[1]
+    out = {r: both[r][False] for r in range(2)}
     assert torch.equal(out[0][0], out[1][0])
+    # the bucketed form (three all-reduces per step, in the order the native backward completes its gradients: decoder + final
+    # layer, encoder blocks 3-5, encoder blocks 0-2) gives the single all-reduce's result bit for bit, on every rank
+    for r in range(2):
+        flat_b, losses_b, calls_b, ranges = both[r][True]
+        assert torch.equal(flat_b, out[r][0]) and losses_b == out[r][1]
+        assert calls_b == 6 and both[r][False][2] == 2 and both[r][False][3] == [(0, 1769905)]
+        assert len(ranges) == 3 and sorted(ranges) == [ranges[2], ranges[1], ranges[0]]           # tail, middle, head
+        assert ranges[2][0] == 0 and ranges[2][1] == ranges[1][0] and ranges[1][1] == ranges[0][0] and ranges[0][1] == 1769905
+        assert ranges[2][1] - ranges[2][0] < 20000 < ranges[0][1] - ranges[0][0] < ranges[1][1] - ranges[1][0]
     from mm_masking_amd import train_icp_weights as trn
     model, p = _policy(seed=10)
     assert not model.global_minmax               # single process: nothing to reduce over
@@ -221,7 +236,8 @@ def _fit_worker(rank, world, port, out, ckpt_dir):
         hist = trn.fit(model, _Batches(rank, 2, 0), _Batches(rank, 1, 100), opt, p, ckpt_dir, grad_sync=sync,
                        is_main=(rank == 0), log=lambda *_: None)
         flat = torch.cat([q.detach().flatten() for q in model.parameters()])
-        out[rank] = (flat, hist.get("final_acc"), n_forward[0], sorted(os.listdir(ckpt_dir)) if rank == 0 else None)
+        out[rank] = (flat, hist.get("final_acc"), n_forward[0], sorted(os.listdir(ckpt_dir)) if rank == 0 else None,
+                     (hist["best_norm"], hist["acc"]))
     finally:
         dist.destroy_process_group()
 
@@ -237,6 +253,9 @@ def test_fit_two_ranks_final_validation_on_all_ranks(tmp_path):
     mp.spawn(_fit_worker, args=(world, port, out, str(tmp_path)), nprocs=world, join=True)
     assert out[0][2] == out[1][2] > 0
     assert out[0][1] is not None and out[1][1] is not None          # final validation ran on both
+    # the validation metric is the mean over the ranks' shards (the reference selects on the whole validation set,
+    # train_icp_weights.py:534-537): every rank holds the same history and takes the same best-policy decisions
+    assert out[0][4] == out[1][4] and out[0][1] == out[1][1]
     assert torch.equal(out[0][0], out[1][0])                        # identical (best) weights everywhere
     best = torch.load(os.path.join(str(tmp_path), "best_policy.pt"), weights_only=True)
     # best_policy.pt holds the state_dict in module order: same order as parameters()

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _step(rank, world, global_batch, global_minmax):
+def _step(rank, world, global_batch, global_minmax, overlap=False):
     from mm_masking_amd import ddp, synthetic
     from mm_masking_amd import train_icp_weights as trn
     from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
@@ -34,7 +34,7 @@ def _step(rank, world, global_batch, global_minmax):
     torch.manual_seed(100 + rank)                       # different init per rank on purpose: rank 0's is broadcast
     model = LearnICPWeightPolicy(params).to(dev)
     model.train()
-    sync = ddp.FlatGradSync(model)
+    sync = ddp.FlatGradSync(model, overlap=overlap)
     sync.sync_params(0)
     idx = ddp.shard_indices(global_batch, rank, world)
     raw = synthetic.make_batch(idx, device=dev, m_valid=3000, m_pad=3072, density="sparse")
@@ -45,6 +45,9 @@ def _step(rank, world, global_batch, global_minmax):
     opt = trn.make_optimizer(model, params)
     loss, _ = trn.train_step(model, batch, opt, lw, dev, grad_sync=sync)
     torch.cuda.synchronize()
+    if overlap:     # three collectives, each behind its own event of THIS step's native backward
+        from mm_masking_amd import unet_hip
+        assert sync.calls == 3 and len(sync.buckets_last) == 3 and unet_hip.GRAD_BUCKET_PASSES[0] == sync._armed_at + 1
     return sync.flat.detach().cpu().clone(), float(loss)
 
 
@@ -53,6 +56,10 @@ def _worker(rank, world, port, global_batch, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         flat, loss = _step(rank, world, global_batch, True)
+        # the same step with the gradient block reduced in the backward's three completion buckets on a communication stream
+        # (ddp.FlatGradSync(overlap=True), mmk_unet_backward_buckets): the same gradient, bit for bit
+        flat_b, loss_b = _step(rank, world, global_batch, True, overlap=True)
+        assert torch.equal(flat, flat_b) and loss == loss_b
         lt = torch.tensor([loss], dtype=torch.float64)
         dist.all_reduce(lt)
         out[rank] = (flat.numpy(), float(lt.item()) / world)

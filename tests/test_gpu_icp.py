@@ -331,6 +331,77 @@ def test_config5_50k_fp32_gate():
     assert np.abs(Tg[:, :2, 3]).max() < 0.1 and np.abs(Tg[:, 1, 0]).max() < 5e-3
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_config5_50k_through_the_policy_with_override_mask(mode):
+    """BASELINE.json configs[4] as SURVEY.md 8d writes it: B = 4, M = 50 000 valid / 50 176 padded, fp32 end to end, the U-Net
+    bypassed with ``override_mask=ones`` -- i.e. the ``generate_baseline`` call path
+    (/root/reference/mm_masking/train_icp_weights.py:298-319 -> icp_weight_policy.py:136,188-189,277-288): through
+    ``LearnICPWeightPolicy.forward`` in eval mode (ICP_alg_inference: 50 iterations, tolerance 1e-5) and in train mode
+    (ICP_alg: 10 iterations), under no_grad as upstream.  Correspondences bit-exact, pose within 1e-3 m / 1e-4 rad of the CPU
+    restatement fed the oracle's own extract_weights of the same mask."""
+    from mm_masking_amd import train_icp_weights as trn
+    from mm_masking_amd.icp_weight_policy import LearnICPWeightPolicy
+    from oracle import radar_ref, train_ref
+    B, MV, MP, N, NV = 4, 50000, 50176, 5120, 4500
+    raws = [synthetic.make_pair(100 + b, m_valid=MV, m_pad=MP, pos_std=0.5, rot_std=0.03) for b in range(B)]
+    tgt = np.stack([r["map_pc"] for r in raws])
+    assert tgt.shape == (B, MP, 6)
+    rng = np.random.default_rng(0)
+    src = np.zeros((B, N, 3), np.float32)
+    T0 = np.stack([r["T_init"] for r in raws])
+    for b in range(B):
+        sel = rng.choice(MV, NV, replace=False)
+        src[b, :NV, :2] = tgt[b, sel, :2] + rng.normal(0, 0.03, (NV, 2))
+    lf = {"name": "huber", "metric": 1.0}
+    params = trn.default_params(DEV)
+    params.update({"icp_type": "pt2pl", "icp_loss_fn": lf, "max_iter": 10})
+    torch.manual_seed(0)
+    model = LearnICPWeightPolicy(params).to(DEV)
+    assert model.ICP_alg.nn_search == model.ICP_alg_inference.nn_search == ICP.NN_SEARCH_OVERRIDE
+    model.train() if mode == "train" else model.eval()
+    ones = torch.ones(B, 640, 640)
+    zeros = torch.zeros(B, 640, 640)
+    scan = {"fft_data": zeros, "fft_cfar": zeros, "raw_pc": torch.from_numpy(src), "filtered_pc": torch.from_numpy(src)}
+    batch = {"loc_data": scan, "map_data": {"pc": torch.from_numpy(tgt)},
+             "transforms": {"T_ml_init": torch.from_numpy(T0), "T_ml_gt": torch.eye(4).repeat(B, 1, 1)}}
+    with torch.no_grad():
+        T, mask, _ = model(scan, batch["map_data"], torch.from_numpy(T0).to(DEV), override_mask=ones)
+    alg = model.ICP_alg if mode == "train" else model.ICP_alg_inference
+    idx_gpu = alg.last_state["idx"][0].cpu().numpy()
+    assert torch.equal(mask.cpu(), ones)                        # ones / amax(ones)
+    # the oracle on the same inputs: its own bilinear sampling of the same mask, then the CPU dICP
+    w_ref = radar_ref.extract_weights(ones.numpy(), src)[0]
+    assert (w_ref[:, :NV] == 1).all() and (w_ref[:, NV:] == 0).all()
+    K = 10 if mode == "train" else 50
+    ref = dicp_ref.ICPRef("pt2pl", differentiable=False, max_iterations=K, tolerance=1e-5)
+    out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.from_numpy(T0), weight=torch.from_numpy(w_ref),
+                  trim_dist=5.0, loss_fn=lf, dim=2)
+    # a pair that froze keeps the correspondences of its last active iteration (frozen pairs skip the search)
+    act = np.stack([a.numpy() for a in out["hist"]["active"]])           # (iterations, B)
+    for b in range(B):
+        k_last = int(np.nonzero(act[:, b])[0].max())
+        np.testing.assert_array_equal(idx_gpu[b], out["hist"]["idx"][k_last][b].numpy(), err_msg="pair %d" % b)
+    Tg, Tr = T.cpu().numpy(), out["T"].numpy()
+    assert np.abs(Tg[:, :2, 3] - Tr[:, :2, 3]).max() <= 1e-3
+    assert np.abs(np.arctan2(Tg[:, 1, 0], Tg[:, 0, 0]) - np.arctan2(Tr[:, 1, 0], Tr[:, 0, 0])).max() <= 1e-4
+    assert np.abs(Tg[:, :2, 3]).max() < 0.1 and np.abs(Tg[:, 1, 0]).max() < 5e-3          # and it localises
+    if mode == "eval":
+        assert alg.last_iterations < 50 and out["num_iter"] < 50      # both stopped on the tolerance
+    # the same through generate_baseline itself (the "ones" branch: every mask-loss weight 0)
+    li, lo = trn.generate_baseline(model, [batch], baseline_type="val" if mode == "eval" else "train", device=DEV,
+                                   loss_weights={"icp": 1.0, "icp_rot": 1.0, "icp_trans": 1.0, "fft": 0.0, "mask_pts": 0.0, "cfar": 0.0,
+                                                 "num_pts": 0.0})
+    eye = torch.eye(4).repeat(B, 1, 1)
+    if mode == "eval":
+        want_i = float(train_ref.eval_validation_loss(torch.from_numpy(T0), eye)[0])
+        want_o = float(train_ref.eval_validation_loss(out["T"], eye)[0])
+    else:
+        lw = dict(train_ref.DEFAULT_LOSS_WEIGHTS, mask_pts=0.0)
+        want_i = float(train_ref.eval_training_loss(torch.from_numpy(T0), ones, None, eye, zeros, None, None, None, lw)[0])
+        want_o = float(train_ref.eval_training_loss(out["T"], ones, None, eye, zeros, None, None, None, lw)[0])
+    assert abs(li - want_i) <= 1e-6 * max(1.0, abs(want_i)) and abs(lo - want_o) <= 2e-5 + 1e-3 * abs(want_o), (li, want_i, lo, want_o)
+
+
 # ----------------------------------------------------------------------------- known answers built outside our code
 import dicp_kat as kat  # noqa: E402
 

@@ -180,31 +180,35 @@ def test_device_loader_draws_from_its_own_generator(golden_dir, tmp_path):
 
 def test_host_read_rows_roll_and_columns(tmp_path):
     from mm_masking_amd import _lib
-    L = _lib.lib()
-    rng = np.random.default_rng(1)
-    img = rng.integers(0, 256, (7, 23), dtype=np.uint8)
-    path = str(tmp_path / "rows.u8")
-    with open(path, "wb") as f:
-        f.write(b"HEAD1234")
-        f.write(img.tobytes())
-    for roll in (0, 3, -2, 7, 9):
-        out = np.zeros((7, 10), np.uint8)
-        _lib.check(L.mmk_host_read_rows(path.encode(), 8, 7, 23, 5, 10, roll, out.ctypes.data))
-        assert np.array_equal(out, np.roll(img[:, 5:15], roll, axis=0)), roll
-    full = np.zeros((7, 23), np.uint8)
-    _lib.check(L.mmk_host_read_rows(path.encode(), 8, 7, 23, 0, 23, 0, full.ctypes.data))
-    assert np.array_equal(full, img)
-    assert L.mmk_host_read_rows(path.encode(), 8, 8, 23, 0, 23, 0, full.ctypes.data) != 0 and b"shorter" in L.mmk_last_error()
-    assert L.mmk_host_read_rows(str(tmp_path / "missing").encode(), 0, 1, 4, 0, 4, 0, full.ctypes.data) != 0
-    # the batched form: 12 jobs on 3 threads, then one bad job among them
-    outs = [np.zeros((7, 10), np.uint8) for _ in range(12)]
-    jobs = (_lib.ReadJob * 12)()
-    pb = path.encode()
-    for k, o in enumerate(outs):
-        jobs[k].path, jobs[k].header_bytes, jobs[k].rows, jobs[k].row_bytes = pb, 8, 7, 23
-        jobs[k].col0, jobs[k].ncols, jobs[k].roll, jobs[k].dst = k, 10, k - 4, o.ctypes.data
-    _lib.check(L.mmk_host_read_rows_batch(jobs, 12, 3))
-    for k, o in enumerate(outs):
-        assert np.array_equal(o, np.roll(img[:, k:k + 10], k - 4, axis=0)), k
-    jobs[5].rows = 9
-    assert L.mmk_host_read_rows_batch(jobs, 12, 3) != 0 and b"1 of 12 jobs failed" in L.mmk_last_error()
+    import host_read_checks
+    host_read_checks.run(_lib.lib(), str(tmp_path), ReadJob=_lib.ReadJob)
+
+
+def test_host_read_rows_under_address_and_ub_sanitizers(tmp_path):
+    """The host half of the loader (csrc/mmk_loader_host.inc: pread loops, a stack block, C threads drawing jobs from a shared
+    counter) compiled for the CPU with -fsanitize=address,undefined and driven through the same checks as the product library
+    (tests/host_read_checks.py), in a child interpreter with the sanitizer runtime pre-loaded.  GPU sanitizer runs are not
+    available on the pool; this half needs no GPU."""
+    import shutil
+    import subprocess
+    import sys
+    import pytest
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libmmk_loader_san.so")
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-shared", "-fPIC", "-I", os.path.join(root, "include"), "-o", so,
+                           os.path.join(root, "mm_masking_amd", "csrc", "mmk_loader_host_san.cpp"), "-lpthread"])
+    asan = subprocess.check_output([gxx, "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "host_read_checks.py"), so, str(work)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "host_read_checks ok" in r.stdout, r.stdout[-3000:]
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, r.stdout[-3000:]
