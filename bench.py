@@ -463,13 +463,13 @@ def main():
             streak = streak + 1 if d_s <= 1.10 * best else 0
             if not dist_on and i >= 5 and streak >= 5:
                 break
-    progress("warm-up: %d steps" % args.warmup)
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
     import gc
     gc.collect()
     gc.freeze()      # keep the collector from re-scanning the long-lived objects inside the timed region
+    progress("warm-up: %d steps" % args.warmup)
+    for i in range(args.warmup):
+        one_step(i)
+    fence()          # (nothing but this fence between the warm-up and the timed steps: an idle GPU drops its clocks)
     progress("timing %d steps" % args.steps)
     cap = args.steps * ICP_ITERS + 8
     _lib.check(L.mmk_nn_profile_begin(cap))

@@ -788,6 +788,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     const int t_end = (t_begin + tiles_per_xcd < total_tiles) ? t_begin + tiles_per_xcd : total_tiles;
     int tile = t_begin + (blockIdx.x >> 3);
     if (tile >= t_end) return;
+    if (a.stagger > 0 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
 
     u32x4 rin[RIN], rw[RW];
     // Per lane and granule, once: position inside the halo tile.  Inside the loop an address is "uniform halo origin of the
@@ -871,10 +873,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     const bf16 *b_base = in_tile + ((size_t)(wn * WT + (lane & 15))) * PK + 8 * (lane >> 4);
     const bf16 *a_base = w_lds + ((size_t)(wm * MT) * 64 + lane) * 8;
 
-    int chunk = 0;
-    load_in(tile, 0);
-    load_w(0);
-    while (true) {
+    // registers of a loaded stage -> LDS
+    auto write_stage = [&]() {
 #pragma unroll
         for (int i = 0; i < RIN; ++i) {
             const int g = tid + i * DEEP_THREADS;
@@ -885,7 +885,21 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
             const int g = tid + i * DEEP_THREADS;
             if (g < NW) reinterpret_cast<u32x4 *>(w_lds)[g] = rw[i];
         }
-        __syncthreads();
+    };
+    // The first stage goes into LDS in front of the loop, every later one at the loop's END.  With the LDS write at the loop's
+    // head (rounds 1-4) the head merged two states of the memory counter: the prologue's outstanding loads, and -- on the back
+    // edge -- the epilogue's outstanding STORES.  hipcc covered the first with s_waitcnt vmcnt(10) ... vmcnt(0) in front of the
+    // ds_writes, and since loads and stores share that counter the same waits made every block drain its output stores right
+    // behind issuing them, with the matrix cores idle and every CU of the chip doing so at the same moment: the "epilogue phase"
+    // that the round-4 ablations priced at 18-34 us per launch was that drain (an HBM write burst), not the epilogue's own
+    // instructions.  Here the loop head sees no outstanding load on either edge; the stores drain beside the next stage's MFMAs
+    // and are waited for only by that stage's end-of-loop delivery of its prefetch (in-order counter), a whole MFMA phase later.
+    int chunk = 0;
+    load_in(tile, 0);
+    load_w(0);
+    write_stage();
+    __syncthreads();
+    while (true) {
         int ntile = tile, nck = chunk + 1;
         if (nck == nchunk) {
             nck = 0;
@@ -1030,6 +1044,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
             reset_acc();
         }
         if (!has_next) break;
+        __syncthreads();          // every wave is done reading this stage's fragments
+        write_stage();
         __syncthreads();
         tile = ntile;
         chunk = nck;
@@ -1055,7 +1071,12 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     const int per_xcd = (total + 7) / 8;
     int nb = 32 / groups;                                    // one 8-wave block per CU, 32 CUs per XCD
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK, SUBW>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, a, total, per_xcd);
+    ConvArgs b = a;
+    {
+        const char *e = getenv("MMK_DEEP_STAGGER");        // experiment switch (read per call)
+        if (e) b.stagger = atoi(e);
+    }
+    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK, SUBW>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, b, total, per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
@@ -1651,15 +1672,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdF
     const int adv_tx = t_step % tiles_x, adv_ty = (t_step / tiles_x) % tiles_y, adv_b = t_step / tpi;
     int ld_b = t_first / tpi, ld_ty = (t_first % tpi) / tiles_x, ld_tx = t_first % tiles_x;
     int cb = ld_b, cty = ld_ty, ctx = ld_tx;
-    if (t_first < t_end) load_tile(ld_b, ld_ty, ld_tx);
+    // The first tile goes into LDS in front of the loop, every later one at the loop's END (round 5).  With store_tile() at the
+    // loop's head the head merged the prologue's outstanding loads with the back edge's outstanding dx STORES; hipcc covered the
+    // former with s_waitcnt vmcnt(5) ... vmcnt(0) in front of the ds_writes, which on the back edge made every wave wait for its own
+    // output stores right behind issuing them (loads and stores share the counter).  Now no load is outstanding at the head on
+    // either edge; the stores are waited for one tile later, by the delivery of the next prefetch.
+    if (t_first < t_end) {
+        load_tile(ld_b, ld_ty, ld_tx);
+        store_tile();
+    }
+    __syncthreads();
     for (int t = t_first; t < t_end; t += t_step) {
         const int b = cb;
         const int tx0 = ctx * TW, ty0 = cty * TH;
         const int pix0 = (b * a.H + ty0) * a.W + tx0;
         const bool ok8 = (ty0 + lrow8) < a.H && (tx0 + lcol8) < a.W;
-        __syncthreads();
-        store_tile();
-        __syncthreads();
         // the accumulate target of this tile's epilogue, ahead of the next tile's operands in the load queue
         u32x4 e8_acc = {0u, 0u, 0u, 0u};
         if constexpr (CX == 8) e8_acc = *((ok8 && a.accumulate_dx) ? reinterpret_cast<const u32x4 *>(a.dx + (long)(pix0 + lpix8) * 8) : &g_zero16);
@@ -1774,6 +1801,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_bwd_fused_kernel(const BwdF
                 *dst = outv;
             }
         }
+        if (t + t_step >= t_end) break;
+        __syncthreads();          // every wave is done with this tile's LDS image
+        store_tile();
+        __syncthreads();
     }
 
     // ---- flush the block's partial slice: [tap][co < CG][ci < CX] weight sums, then CG bias sums

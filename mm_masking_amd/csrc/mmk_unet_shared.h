@@ -40,6 +40,7 @@ struct ConvArgs {
     // 16-channel tiles per group of the packing, 0 = the kernel's own width)
     unsigned hash_base = 0;
     int wpack_mtb = 0;
+    int stagger = 0;       // >= 64-channel kernel: every other block of an XCD starts this many 1 024-cycle sleeps late (de-phasing)
 };
 
 // Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index e4 (a multiple of 4): four
@@ -48,8 +49,7 @@ struct ConvArgs {
 // rate on the VALU: three of them per four values were half of the forward epilogues of the issue-bound kernels (switching
 // dropout off moved the thin 640 x 640 forward launches by 13-30 us each).  Nothing downstream depends on
 // WHICH elements are dropped -- the backward kernels read the mask back from the stored activation -- only on the rate and
-// on independence: checked offline on 4M indices and three seeds (drop rates within 0.5 % of thr / 65536; correlation between
-// the four draws, between neighbouring groups, pixels and image rows all <= 1e-3; scripts/dropout_hash_check.py).
+// on independence (scripts/dropout_hash_check.py; the chain itself: below).
 struct DropoutParams {
     unsigned thr;      // drop when the 16-bit draw is below thr
     float inv_keep;    // 1 / (1 - thr / 65536): exactly unbiased for the quantised probability
@@ -63,18 +63,25 @@ __host__ __device__ inline DropoutParams dropout_params(float p)
     return d;
 }
 
+// Round 5: every step is a BIJECTION of the 32-bit state.  A 24-bit multiply alone keeps the low 24 bits of its
+// input, so the round-4 chain produced at most 2^24 different draw quadruples whatever the seed and the index: at the group
+// counts of the 640 x 640 layers (2^24.6) 78 % of the groups shared their draws with another group, and group 2^24 + k repeated
+// group k + 1.  v_mad_u32_u24 with the state itself as the addend is lo24 * C + x = lo24 * (C + 1) + (hi8 << 24), one-to-one for
+// EVEN C -- same instruction count, same full-rate pipe.  scripts/dropout_hash_check.py on 2^25 groups: all quadruples distinct,
+// byte histograms at chi^2 / dof = 1.0, |correlation| <= 5e-4 within a group, between neighbours and between the masks of
+// consecutive layer seeds.
 __device__ __forceinline__ void dropout_draws4(unsigned seed, unsigned e4, unsigned (&d)[4])
 {
-    const unsigned i = e4 >> 2;                       // group number; bits above 2^24 go into the seed
-    unsigned h = __umul24(i, 0x9E3779u) + (seed + __umul24(i >> 24, 0x9E3779u));
+    const unsigned i = e4 >> 2;                       // group number
+    unsigned h = __umul24(i, 0x9E3779u) + (seed + (i & 0xff000000u));
     h ^= h >> 13;
-    h = __umul24(h, 0x85EBCBu);
+    h = __umul24(h, 0x85EBCAu) + h;
     h ^= h >> 11;
-    h = __umul24(h, 0xC2B2AFu);
+    h = __umul24(h, 0xC2B2AEu) + h;
     h ^= h >> 15;
     unsigned g = h ^ 0x85ebca6bU;
     g ^= g >> 12;
-    g = __umul24(g, 0x7FEB35u);
+    g = __umul24(g, 0x7FEB34u) + g;
     g ^= g >> 14;
     d[0] = h & 0xffffu; d[1] = h >> 16; d[2] = g & 0xffffu; d[3] = g >> 16;
 }

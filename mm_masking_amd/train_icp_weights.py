@@ -270,7 +270,8 @@ def _check_device_errors(device):
     ICP call: dICP/ICP.py).  At the end of a pass nothing follows, so wait for the calls in flight and raise here: a flagged
     call's poses must not reach a checkpoint or a reported metric unnoticed (one synchronisation per epoch)."""
     if torch.device(device).type == "cuda":
-        from .dICP import ICP as icp_mod
+        import importlib
+        icp_mod = importlib.import_module(__package__ + ".dICP.ICP")     # the module (the package re-exports the class under its name)
         icp_mod.check_errors(wait=True)
 
 

@@ -371,7 +371,8 @@ def test_config5_50k_through_the_policy_with_override_mask(mode):
     assert torch.equal(mask.cpu(), ones)                        # ones / amax(ones)
     # the oracle on the same inputs: its own bilinear sampling of the same mask, then the CPU dICP
     w_ref = radar_ref.extract_weights(ones.numpy(), src)[0]
-    assert (w_ref[:, :NV] == 1).all() and (w_ref[:, NV:] == 0).all()
+    # (1 inside the image, less on its border rows / columns and outside: the map reaches beyond the 76 m half-width; 0 on zero rows)
+    assert (w_ref[:, NV:] == 0).all() and (w_ref[:, :NV] == 1).mean() > 0.9
     K = 10 if mode == "train" else 50
     ref = dicp_ref.ICPRef("pt2pl", differentiable=False, max_iterations=K, tolerance=1e-5)
     out = ref.icp(torch.from_numpy(src), torch.from_numpy(tgt), T_init=torch.from_numpy(T0), weight=torch.from_numpy(w_ref),

@@ -56,8 +56,9 @@ def test_config2_b32_full_step_parity():
     assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
     assert res["loss_rel_err"] < 1e-4, res
     assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
-    # parameter gradients, bf16 storage vs fp32 (stated budget; measured 0.036 / 0.979: DESIGN.md §5b)
-    assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
+    # parameter gradients, bf16 storage vs fp32: measured global relative L2 0.0162, worst per-tensor cosine 0.9939
+    # (encoder.4.0.bias); bounds = measured + 30 %
+    assert res["param_grad_rel"] < 0.022 and res["param_grad_cos_min"] > 0.992, res
 
 
 def test_config2_dim3_full_step_parity():
@@ -72,7 +73,7 @@ def test_config2_dim3_full_step_parity():
     assert res["pose_trans_err"] <= 1e-3 and res["pose_rot_err"] <= 1e-4, res
     assert res["loss_rel_err"] < 1e-4, res
     assert res["mask_grad_rel"] <= 2e-3 and res["mask_grad_rel_taps"] <= 2e-3, res
-    assert res["param_grad_rel"] < 0.08 and res["param_grad_cos_min"] > 0.95, res
+    assert res["param_grad_rel"] < 0.022 and res["param_grad_cos_min"] > 0.992, res          # (measured 0.0166 / 0.9938)
 
 
 @pytest.mark.parametrize("norm_weights", [False, True])
@@ -93,15 +94,22 @@ def test_training_trajectory_bf16_hip_vs_fp32_oracle(norm_weights):
     print({k: v for k, v in res.items() if k not in ("log", "loss_hip", "loss_ref")})
     # training moved: the loss fell on both sides, by about the same amount
     assert res["loss_drop_ref"] > 0 and res["loss_drop_hip"] > 0, res
-    assert abs(res["loss_drop_hip"] - res["loss_drop_ref"]) < 0.25 * res["loss_drop_ref"], res
-    # step by step the two losses stay together (measured: see DESIGN.md, bands = measured + 30 %)
-    assert res["loss_rel_max"] < (0.02 if not norm_weights else 0.03), res
-    # the metric the reference selects checkpoints by, after training
+    # (measured on MI355X, norm_weights False / True: loss drop 0.00756 vs 0.00727 / 0.3844 vs 0.3813)
+    assert abs(res["loss_drop_hip"] - res["loss_drop_ref"]) < 0.10 * res["loss_drop_ref"], res
+    # step by step the two losses stay together: measured max relative difference over the 30 steps 3.2e-4 / 1.2e-3 (it grows
+    # with the step count: 3e-6 / 3e-4 at step 0); bands = 2.5 x / 2 x the measurement (the fp32 side's summation order depends
+    # on the host's core count)
+    assert res["loss_rel_max"] < (8e-4 if not norm_weights else 2.5e-3), res
+    # the metric the reference selects checkpoints by (eval_validation_loss norm on a held-out batch, 50-iteration inference ICP),
+    # after training: measured 2.058118 vs 2.058108 / 2.054342 vs 2.054358
     va, vb = res["val_hip_after"][0], res["val_ref_after"][0]
-    assert abs(va - vb) < 0.05 * max(vb, 0.02), res
-    # both runs moved the parameters about equally far, and mostly in the same direction
-    assert 0.8 < res["distance_moved_hip"] / res["distance_moved_ref"] < 1.25, res
-    assert res["update_cosine"] > 0.5, res
+    assert abs(va - vb) < 2e-4 * vb, res
+    assert abs(res["val_ref_after"][0] - res["val_ref_before"][0]) > 10 * abs(va - vb), res      # ... and training moved it by more
+    # both runs moved the parameters equally far (measured ratio 1.017 / 1.019) and in the same direction (cosine of the two
+    # updates 0.916 / 0.722: Adam turns a gradient's SIGN into a full-size step, so near-zero gradients that bf16 rounds to the
+    # other side pull the cosine down; drift / distance moved 0.41 / 0.75, reported, not asserted)
+    assert 0.95 < res["distance_moved_hip"] / res["distance_moved_ref"] < 1.06, res
+    assert res["update_cosine"] > (0.85 if not norm_weights else 0.6), res
 
 
 def test_training_step_is_bit_reproducible():
