@@ -581,27 +581,20 @@ def main():
         valid = valid_scan_points(trn.prepare_batch(raws[0], params, max_loc_pts=N_PAD))
         # bytes a launch actually reads + writes: the scanned source rows (x,y), the target planes, one (idx, d2) per row
         alg_bytes_read = active_pairs * (4 * DIM * scanned + 4 * DIM * M_PAD + 8 * N_PAD)
-        mfma_nn = model.ICP_alg.nn_search == "brute" and DIM == 2 and os.environ.get("MMK_NN_MFMA", "1") != "0"
         if model.ICP_alg.nn_search == "grid":
             nn_kernel = "grid_nn_kernel<2>"
         else:
-            nn_kernel = "nn_mfma_kernel<2>" if mfma_nn else "nn_prefilter_kernel<2, 2, 16>"
-        if mfma_nn:
-            # every pair is one element of a v_mfma_f32_32x32x16_bf16 result tile: 1 024 pairs per instruction, one instruction
-            # per 32 cycles and SIMD (MI355X_MICROARCH.md, cycle constants), 1 024 SIMDs at 2.4 GHz
-            peak_pairs = 1024 * 1024 / 32.0 * 2.4e9
-            binding = {"pipe": "bf16 matrix cores (pair pricing) + fp32 VALU (chunk minima, exact re-scan)",
-                       "pair_evals_per_s": evals / nn_avg_s, "peak_pair_evals_per_s": peak_pairs,
-                       "frac": evals / nn_avg_s / peak_pairs,
-                       "equivalent_dense_bf16_tflops": evals / nn_avg_s * 32 / 1e12,
-                       "note": "16 k-slots (2 x 16 flop) per pair: exact three-way bf16 splits of -2p, t and |t|^2, fp32 accumulation; "
-                               "the fp32 VALU kernel of rounds 1-2 (MMK_NN_MFMA=0) issues 3.3 vector instructions per 64 pairs, this "
-                               "one 1.4 (profiles/r04_nn_pmc_counters.json)"}
-        else:
-            binding = {"pipe": "fp32 VALU", "pair_evals_per_s": evals / nn_avg_s, "achieved_tflops": evals * 6 / nn_avg_s / 1e12,
-                       "peak_tflops": VALU_PEAK_TFLOPS, "frac": evals * 6 / nn_avg_s / 1e12 / VALU_PEAK_TFLOPS, "flop_per_eval": 6,
-                       "note": "6 = the normative distance (2 sub, mul, fma, compare); the pre-filtered scan issues 3 vector "
-                               "instructions per evaluation (2 fma + min)"}
+            nn_kernel = "nn_mfma_kernel<2>"
+        # every pair is one element of a v_mfma_f32_32x32x16_bf16 result tile: 1 024 pairs per instruction, one instruction
+        # per 32 cycles and SIMD (MI355X_MICROARCH.md, cycle constants), 1 024 SIMDs at 2.4 GHz
+        peak_pairs = 1024 * 1024 / 32.0 * 2.4e9
+        binding = {"pipe": "bf16 matrix cores (pair pricing) + fp32 VALU (chunk minima, exact re-scan)",
+                   "pair_evals_per_s": evals / nn_avg_s, "peak_pair_evals_per_s": peak_pairs,
+                   "frac": evals / nn_avg_s / peak_pairs,
+                   "equivalent_dense_bf16_tflops": evals / nn_avg_s * 32 / 1e12,
+                   "note": "16 k-slots (2 x 16 flop) per pair: exact three-way bf16 splits of -2p, t and |t|^2, fp32 accumulation; "
+                           "1.1 vector instructions per 64 pairs beside the MFMAs (profiles/r04_nn_pmc_counters.json; the fp32 VALU "
+                           "kernel of rounds 1-2, removed in round 5, issued 3.3)"}
         result = {
             "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

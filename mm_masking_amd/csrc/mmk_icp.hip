@@ -75,9 +75,9 @@ __global__ void pack_target_kernel(const float *__restrict__ tgt, int M, int col
 }
 
 // ------------------------------------------------------------------------------------------
-// I2: brute-force NN with an exact pre-filter, priced on the vector pipe (dim 3; the dim-2 form on the matrix cores follows).
-// One lane owns P transformed source points in VGPRs; the target streams through LDS in planar tiles (wave-uniform
-// ds_read_b128 broadcasts).  Work is cut into units (pair, source block, target range); a persistent 1-D grid walks them with
+// I2: brute-force NN with an exact pre-filter.  The derivation below is the vector-pipe form of rounds 2-3 (kernel removed in
+// round 5: HISTORY.md 5, 9.1); the kernel of this file prices the pairs on the matrix cores (nn_mfma_kernel, further down) with
+// the same unit decomposition, seeds and exact re-scan.  Work is cut into units (pair, source block, target range); a persistent 1-D grid walks them with
 // stride gridDim.x.  Units are numbered so that unit % 8 == pair % 8: blocks of one pair share an XCD (blockIdx % 8 label) and
 // its target planes stay in that L2.  The partial results of the target ranges meet in one 64-bit atomic min per source point
 // on the key (float bits of d2) << 32 | index: d2 >= 0, so unsigned order == float order, and equal distances resolve to the
@@ -152,214 +152,8 @@ __global__ void src_units_kernel(const int32_t *__restrict__ allzero, const int3
     if (c == 0) ucnt[8] = mx;
 }
 
-template <int DIM, int P, int SUB>
-__global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
-    const float *__restrict__ src, const float *__restrict__ tgtp,
-    const float *__restrict__ Tk, const int32_t *__restrict__ active, const int32_t *__restrict__ prev_idx,
-    const int32_t *__restrict__ ulist, const int32_t *__restrict__ ucnt, int ucap, int B,
-    int N, int Mpad, int nsb, int ntu, int tiles_per_unit, int total_units, float kappa,
-    unsigned long long *__restrict__ packed)
-{
-    __shared__ __attribute__((aligned(16))) float lt[DIM + 1][NN_TILE];
-    const int tid = threadIdx.x;
-    const int ntiles = Mpad / NN_TILE;
-    // (zero-row deduplication on: the units are the listed source blocks x target ranges)
-    if (ulist != nullptr) total_units = ucnt[8] * ntu * 8;
-
-    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
-        const int xcd = u & 7;
-        int rest = u >> 3;
-        const int tu = rest % ntu;
-        rest /= ntu;
-        int sb, b;
-        if (ulist != nullptr) {
-            if (rest >= ucnt[xcd]) continue;
-            const int code = ulist[(size_t)xcd * ucap + rest];
-            sb = code & 0xfff;
-            b = code >> 12;
-        } else {
-            sb = rest % nsb;
-            b = (rest / nsb) * 8 + xcd;
-        }
-        if (b >= B) continue;
-        if (active != nullptr && active[b] == 0) continue;
-
-        float T[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T[i] = Tk[(size_t)b * 16 + i];
-        const float *tb = tgtp + (size_t)b * DIM * Mpad;
-
-        float p[P][DIM], a[P][DIM], pn[P], brun[P], cur[P];
-        int pidx[P], jj[P];
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = sb * (NN_THREADS * P) + q * NN_THREADS + tid;
-            pidx[q] = i;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            if (i < N) {
-                const float *sp = src + ((size_t)b * N + i) * 3;
-                s0 = sp[0];
-                s1 = sp[1];
-                s2 = sp[2];
-            }
-            const float s[3] = {s0, s1, s2};
-            transform_point<DIM>(T, s, p[q]);
-            float n2 = p[q][0] * p[q][0] + p[q][1] * p[q][1];
-            if constexpr (DIM == 3) n2 += p[q][2] * p[q][2];
-            pn[q] = n2;
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) a[q][c] = -2.0f * p[q][c];
-            // Any e_j is an upper bound of the minimum: start from the target this point was matched with in the
-            // previous iteration (the pose moves little between iterations), so that from the second iteration
-            // on hardly any chunk but the ones that matter is flagged.  Same fma chain as in the scan below.
-            float b0 = INFINITY;
-            if (prev_idx != nullptr && i < N) {
-                const int j = prev_idx[(size_t)b * N + i];
-                if (j >= 0 && j < Mpad) {
-                    const float jx = tb[j], jy = tb[(size_t)Mpad + j];
-                    float jn = __builtin_fmaf(jy, jy, jx * jx);
-                    float e = 0.f;
-                    if constexpr (DIM == 3) {
-                        const float jz = tb[(size_t)2 * Mpad + j];
-                        jn = __builtin_fmaf(jz, jz, jn);
-                        e = __builtin_fmaf(jz, a[q][2], __builtin_fmaf(jy, a[q][1], jn));
-                    } else {
-                        e = __builtin_fmaf(jy, a[q][1], jn);
-                    }
-                    b0 = __builtin_fmaf(jx, a[q][0], e);
-                    b0 = (b0 == b0) ? b0 : INFINITY;
-                }
-            }
-            brun[q] = b0;
-            cur[q] = INFINITY;
-        }
-
-        const int t0 = tu * tiles_per_unit;
-        const int t1 = min(ntiles, t0 + tiles_per_unit);
-#pragma unroll
-        for (int q = 0; q < P; ++q) jj[q] = t0 * NN_TILE;
-
-        for (int t = t0; t < t1; ++t) {
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                *reinterpret_cast<float4 *>(&lt[c][tid * 4]) =
-                    *reinterpret_cast<const float4 *>(tb + (size_t)c * Mpad + (size_t)t * NN_TILE + tid * 4);
-            {   // |t|^2 of the four targets this thread staged (no norm plane in memory: it would add a third to the
-                // bytes a launch fetches)
-                const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][tid * 4]);
-                const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][tid * 4]);
-                float4 vn;
-                vn.x = __builtin_fmaf(vy.x, vy.x, vx.x * vx.x);
-                vn.y = __builtin_fmaf(vy.y, vy.y, vx.y * vx.y);
-                vn.z = __builtin_fmaf(vy.z, vy.z, vx.z * vx.z);
-                vn.w = __builtin_fmaf(vy.w, vy.w, vx.w * vx.w);
-                if constexpr (DIM == 3) {
-                    const float4 vz = *reinterpret_cast<const float4 *>(&lt[2][tid * 4]);
-                    vn.x = __builtin_fmaf(vz.x, vz.x, vn.x);
-                    vn.y = __builtin_fmaf(vz.y, vz.y, vn.y);
-                    vn.z = __builtin_fmaf(vz.z, vz.z, vn.z);
-                    vn.w = __builtin_fmaf(vz.w, vz.w, vn.w);
-                }
-                *reinterpret_cast<float4 *>(&lt[DIM][tid * 4]) = vn;
-            }
-            __syncthreads();
-            unsigned w[P];
-#pragma unroll
-            for (int q = 0; q < P; ++q) w[q] = 0u;
-#pragma unroll 2
-            for (int c = 0; c < NN_TILE / PF_CH; ++c) {
-                float m[P];
-#pragma unroll
-                for (int hf = 0; hf < PF_CH / SUB; ++hf) {
-                    float tx[SUB], ty[SUB], tz[SUB], tn[SUB];
-#pragma unroll
-                    for (int h = 0; h < SUB / 4; ++h) {
-                        const int o = c * PF_CH + hf * SUB + h * 4;
-                        const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o]);
-                        const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o]);
-                        const float4 vn = *reinterpret_cast<const float4 *>(&lt[DIM][o]);
-                        tx[h * 4 + 0] = vx.x; tx[h * 4 + 1] = vx.y; tx[h * 4 + 2] = vx.z; tx[h * 4 + 3] = vx.w;
-                        ty[h * 4 + 0] = vy.x; ty[h * 4 + 1] = vy.y; ty[h * 4 + 2] = vy.z; ty[h * 4 + 3] = vy.w;
-                        tn[h * 4 + 0] = vn.x; tn[h * 4 + 1] = vn.y; tn[h * 4 + 2] = vn.z; tn[h * 4 + 3] = vn.w;
-                        if constexpr (DIM == 3) {
-                            const float4 vz = *reinterpret_cast<const float4 *>(&lt[2][o]);
-                            tz[h * 4 + 0] = vz.x; tz[h * 4 + 1] = vz.y; tz[h * 4 + 2] = vz.z; tz[h * 4 + 3] = vz.w;
-                        } else {
-                            tz[h * 4 + 0] = tz[h * 4 + 1] = tz[h * 4 + 2] = tz[h * 4 + 3] = 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < P; ++q) {
-                        auto ev = [&](int j) -> float {
-                            float e = __builtin_fmaf(ty[j], a[q][1], tn[j]);
-                            if constexpr (DIM == 3) e = __builtin_fmaf(tz[j], a[q][2], e);
-                            return __builtin_fmaf(tx[j], a[q][0], e);
-                        };
-                        float mm = (hf == 0) ? ev(0) : __builtin_fminf(m[q], ev(0));
-#pragma unroll
-                        for (int j = 1; j + 1 < SUB; j += 2) mm = __builtin_fminf(__builtin_fminf(mm, ev(j)), ev(j + 1));
-                        m[q] = __builtin_fminf(mm, ev(SUB - 1));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    brun[q] = __builtin_fminf(brun[q], m[q]);
-                    const float thr = __builtin_fmaf(kappa, pn[q] + __builtin_fmaxf(0.f, brun[q] + pn[q]), brun[q]);
-                    w[q] |= (m[q] <= thr) ? (1u << c) : 0u;
-                }
-            }
-            // ---- exact re-scan of this tile's flagged chunks while the tile is in LDS (chunks ascending, tiles
-            // ascending, strict '<': the lowest index among equal distances)
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                unsigned ww = w[q];
-                while (__any(ww != 0u)) {
-                    if (ww != 0u) {
-                        const int c = __ffs((int)ww) - 1;
-                        ww &= ww - 1u;
-                        const int o0 = c * PF_CH;
-                        float best = INFINITY;
-                        int bj = 0;
-#pragma unroll
-                        for (int h = 0; h < PF_CH / 4; ++h) {
-                            const float4 vx = *reinterpret_cast<const float4 *>(&lt[0][o0 + h * 4]);
-                            const float4 vy = *reinterpret_cast<const float4 *>(&lt[1][o0 + h * 4]);
-                            float4 vz = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if constexpr (DIM == 3) vz = *reinterpret_cast<const float4 *>(&lt[2][o0 + h * 4]);
-                            const float d0 = nn_dist<DIM>(vx.x, vy.x, vz.x, p[q]), d1 = nn_dist<DIM>(vx.y, vy.y, vz.y, p[q]);
-                            const float d2 = nn_dist<DIM>(vx.z, vy.z, vz.z, p[q]), d3 = nn_dist<DIM>(vx.w, vy.w, vz.w, p[q]);
-                            if (d0 < best) { best = d0; bj = h * 4 + 0; }
-                            if (d1 < best) { best = d1; bj = h * 4 + 1; }
-                            if (d2 < best) { best = d2; bj = h * 4 + 2; }
-                            if (d3 < best) { best = d3; bj = h * 4 + 3; }
-                        }
-                        if (best < cur[q]) {
-                            cur[q] = best;
-                            jj[q] = t * NN_TILE + o0 + bj;
-                        }
-                    }
-                }
-            }
-        }
-
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = pidx[q];
-            if (i >= N) continue;
-            // (a range that holds no candidate below the starting bound has nothing to add; range 0 always writes, so
-            // that a point whose coordinates are not finite still ends with the oracle's (inf, 0))
-            if (!(cur[q] < INFINITY) && tu != 0) continue;
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(cur[q]) << 32) | (unsigned long long)(unsigned)jj[q];
-            atomicMin(&packed[(size_t)b * N + i], key);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// I2, the default brute-force engine for dim 2: the pre-filter of nn_prefilter_kernel with every (point, target) pair
-// priced on the MATRIX cores.  The fp32 VALU is what bounds the scan above (2 FMAs + 1/2 min per pair); the
+// I2, the brute-force engine: the exact pre-filter above with every (point, target) pair priced on the MATRIX cores.  The fp32 VALU is what bounds the scan above (2 FMAs + 1/2 min per pair); the
 // bf16 matrix pipe runs beside the vector pipe and prices 32 x 32 pairs per v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD),
 // which leaves the vector pipe the chunk minima and the flags only: ~0.8 vector instructions per 64 pairs instead of 3.3.
 //
@@ -375,7 +169,7 @@ __global__ __launch_bounds__(NN_THREADS) void nn_prefilter_kernel(
 // -- the last term for the accumulation of the <= 16 addends in WHATEVER order the hardware adds them, each addition charged
 // 2u of the sum of magnitudes S <= 1.02 (|t|^2 + 2|t||p|) (twice the rounding unit: also covers truncating adders).  With
 // |t| <= |p| + sqrt(D) and 2 |p| sqrt(D) <= |p|^2 + D:   |E_j - e_j| <= G(D_j),  G(D) = u (168.3 |p|^2 + 102.4 D).
-// The fp32 seed of the running bound (e of the previous iteration's correspondent, the fma chain of nn_prefilter_kernel)
+// The fp32 seed of the running bound (e of the previous iteration's correspondent, the fma chain e = fma(tx, a, fma(ty, b, tn)))
 // errs by less than that.  Exactness then follows as above: j* the normative argmin, m the target whose computed value is
 // the running bound b, X = D_m: D_j* <= X (1 + 11u), so
 //      E_j* <= e_m + 11u X + G(X (1 + 11u)) <= b + G(X) + 11u X + G(X(1 + 11u)) <= b + u (336.6 |p|^2 + 216 X),
@@ -1624,20 +1418,8 @@ __global__ void bwd_final_kernel(const double *__restrict__ Gdir, const double *
 // ------------------------------------------------------------------------------------------
 struct NNPlan {
     int Mpad, ntiles, nsb, ntu, tiles_per_unit, total_units, grid, P, ucap;
-    bool mfma;      // the filter runs on the matrix cores (nn_mfma_kernel)
 };
 
-
-// MMK_NN_MFMA=0: price the pairs of the dim-2 filter on the vector pipe (nn_prefilter_kernel) -- A/B measurements
-bool use_nn_mfma()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MMK_NN_MFMA");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
 
 NNPlan nn_plan(int B, int N, int M, int dim)
 {
@@ -1646,21 +1428,20 @@ NNPlan nn_plan(int B, int N, int M, int dim)
     pl.Mpad = (int)mmk::align_up((size_t)M, NN_TILE);
     pl.ntiles = pl.Mpad / NN_TILE;
     pl.nsb = (N + NN_THREADS * pl.P - 1) / (NN_THREADS * pl.P);
-    pl.mfma = use_nn_mfma();
     // Vector-pipe filter: single tiles -- short ranges balance the CUs better, and a range without candidates below the starting
     // bound costs no atomic (5 / 3 / 2 / 1 tiles per unit = 159 / 154 / 147 / 141 us per launch).  Matrix-core filter: a lane's
     // running bound restarts with every unit, and without a seed (the first ICP iteration) every restart flags a "record"
     // sequence of chunks that the exact part then re-scans: 324 / 170 us for the first / a later launch at 1 tile per unit,
     // 265 / 162 at 2, 226 / 157 at 4 (round-3 build before the last tuning; the final kernel: 314 / 148 at 1 tile, 257 / 143 at 2,
     // 195 / 133 at 4, 191 / 141 at 5, 210 / 163 at 10 -- each unit start costs two dependent gathers for the seed).
-    pl.tiles_per_unit = std::min(pl.mfma ? 4 : 1, pl.ntiles);
+    pl.tiles_per_unit = std::min(4, pl.ntiles);
     pl.ntu = (pl.ntiles + pl.tiles_per_unit - 1) / pl.tiles_per_unit;
     const int Bpad = (B + 7) / 8 * 8;
     pl.total_units = Bpad * pl.nsb * pl.ntu;
     pl.ucap = (Bpad / 8) * pl.nsb;             // entries per class of the scanned-block lists (src_units_kernel)
     // persistent grid: 8 blocks of 256 threads per CU on the 256 CUs (LDS 8-12 KB, <= 64 VGPRs); 3 of the matrix-core
     // kernel's (40 KB of LDS each, <= 128 VGPRs)
-    pl.grid = std::min(pl.total_units, pl.mfma ? (dim == 2 ? 1024 : 768) : 2048);
+    pl.grid = std::min(pl.total_units, dim == 2 ? 1024 : 768);
     return pl;
 }
 
@@ -1695,18 +1476,12 @@ int launch_nn(int dim, const float *src, const float *tgtp, const float *Tk, con
         prev_idx = seed_buf;
     }
     constexpr float U = 5.9604645e-8f;       // 2^-24
-    if (pl.mfma && dim == 2) {
+    if (dim == 2) {
         hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist, ucnt,
                            pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 360.0f * U, packed);
-    } else if (pl.mfma) {
+    } else {
         hipLaunchKernelGGL((nn_mfma_kernel<3>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist, ucnt,
                            pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 496.0f * U, packed);
-    } else if (dim == 2) {
-        hipLaunchKernelGGL((nn_prefilter_kernel<2, 2, 16>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist,
-                           ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 48.0f * U, packed);
-    } else {
-        hipLaunchKernelGGL((nn_prefilter_kernel<3, 2, 16>), dim3(pl.grid), dim3(NN_THREADS), 0, st, src, tgtp, Tk, active, prev_idx, ulist,
-                           ucnt, pl.ucap, B, N, pl.Mpad, pl.nsb, pl.ntu, pl.tiles_per_unit, pl.total_units, 64.0f * U, packed);
     }
     MMK_LAUNCH_CHECK();
     if (rec) {

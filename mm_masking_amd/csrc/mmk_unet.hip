@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "mmk_common.h"
 #include "mmk_unet_shared.h"
@@ -399,6 +400,8 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
 //     tiles hit that XCD's L2.
 // native vector type: the HIP uint4 struct is copied by memcpy, which keeps a register ring in scratch
 __device__ u32x4 g_zero16;   // zero-initialised, never written
+__device__ u32x4 g_zero32[2];   // (32 bytes of them)
+__device__ u32x4 g_sink32[2];   // where the unconditional stores of lanes without an output go
 __device__ u32x4 g_sink16[8]; // write-only: where lanes without an output element store
 
 __device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8])
@@ -748,6 +751,23 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
 // on padding.  Wave (wm, wn) owns output channels [wm*MT*16, +MT*16) of tile row wn.
 constexpr int DEEP_THREADS = 512;
 
+// Diagnostic build only (-DMMK_DEEP_STAMPS; scripts/deep_stamps.py): the first 64 blocks record s_memtime at eight points of each
+// of their first MMK_STAMP_STAGES stages, per wave, in LDS, and copy them to a caller's buffer when they exit.  The shipped
+// library contains none of this.
+#ifdef MMK_DEEP_STAMPS
+constexpr int MMK_STAMP_STAGES = 24;
+__device__ unsigned long long *g_deep_stamp_buf = nullptr;
+#define MMK_STAMP(K)                                                                                          \
+    do {                                                                                                      \
+        if (stamp_stage < MMK_STAMP_STAGES) {                                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
+            if (lane == 0) stamp_lds[(wv * MMK_STAMP_STAGES + stamp_stage) * 8 + (K)] = t_;                    \
+        }                                                                                                     \
+    } while (0)
+#else
+#define MMK_STAMP(K) do { } while (0)
+#endif
+
 template <int BM, int NT>
 struct DeepCfg {
     static constexpr int WM = BM >= 128 ? 2 : 1;          // waves along the output channels
@@ -761,17 +781,68 @@ struct DeepCfg {
     static constexpr int NW = NS * MTB * 64;
     static constexpr int RIN = (NIN + DEEP_THREADS - 1) / DEEP_THREADS;
     static constexpr int RW = (NW + DEEP_THREADS - 1) / DEEP_THREADS;
-    static constexpr size_t SMEM = ((size_t)HT * WT * PK + (size_t)NW * 8) * sizeof(bf16) + BM * sizeof(float);   // (+ the bias)
+    static constexpr size_t IN_BYTES = (size_t)HT * WT * PK * sizeof(bf16), W_BYTES = (size_t)NW * 8 * sizeof(bf16);
+    // LDS: the halo tile, `wchunks` stages of packed weights (1, or all CIN / 32 of them when they stay resident), the bias
+    static constexpr size_t smem_core(int wchunks) { return IN_BYTES + (size_t)wchunks * W_BYTES + BM * sizeof(float); }
+#ifdef MMK_DEEP_STAMPS
+    static constexpr size_t smem(int wchunks) { return (smem_core(wchunks) + 15) / 16 * 16 + (size_t)8 * MMK_STAMP_STAGES * 8 * sizeof(unsigned long long); }
+#else
+    static constexpr size_t smem(int wchunks) { return smem_core(wchunks); }
+#endif
 };
 
+// Packed bf16 / int16 helpers of the forward epilogue.  (hipcc has no builtin for v_cvt_pk_bf16_f32 and turns the vector forms of
+// the other two into per-half compares and selects; one instruction per asm statement, so that hipcc pads and schedules around
+// each of them itself.)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned x)          // max(x, 0) on both halves' bit patterns (-0 -> +0)
+{
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+// 0xffff in the halves where the signed 16-bit draw of `words` is >= thr - 32768 (thr1pk = both halves thr - 32768 - 1)
+__device__ __forceinline__ unsigned pk_keep_mask(unsigned words, unsigned thr1pk)
+{
+    unsigned d, m;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(thr1pk), "v"(words));
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(0x000f000fu), "v"(d));
+    return m;
+}
+
+// Round 5.  What the round-4 kernel's stages spent their cycles on (s_memtime stamps of a diagnostic build, scripts/deep_stamps.py,
+// 64 -> 64 at 160 x 160; per stage of ~11 500 cycles, with an epilogue every second stage): issuing the 12 prefetch loads of a
+// thread 2 300-5 400 cycles (the wave sits in the issue of its loads until the CU's memory pipeline has taken them: it cannot
+// start its MFMAs), the MFMA loop 4 800, waiting at the barrier for the waves that got their loads out last 1 700-2 500, writing
+// the stage to LDS 1 200, the epilogue 6 500 forward / 11 000-12 600 data gradient, the second barrier 540-1 900: the matrix
+// cores saw work a third of the time.  This version
+//   * issues the prefetch loads INSIDE the MFMA loop, one or two per tap (a scheduling barrier per tap keeps them there), so no
+//     wave waits in a load burst and all waves reach the barrier together;
+//   * WRES: keeps the packed weights of ALL input-channel chunks in LDS for the whole launch where they fit beside the halo
+//     tile (64 -> 64, 32 -> 64, 64 -> 32: 5 of the 12 loads and LDS writes of every stage gone, and 37 KB per stage and CU of L2
+//     traffic with them);
+//   * writes the next stage to LDS BEFORE the epilogue (the staging registers are dead during it);
+//   * compile-time epilogue roles: R_FWD = bias + ReLU (+ dropout) on packed bf16 pairs (fma with the keep factor folded into the
+//     bias, v_cvt_pk, ReLU as v_pk_max_i16, the dropout mask as saturating packed subtract + arithmetic shift of the hash words:
+//     ~6.8 instead of ~11 vector instructions per output value); R_BWD = ReLU source OR accumulate target, fetched for all
+//     n-tiles right behind the MFMA loop, in front of the barrier and the LDS write (fetched n-tile by n-tile each load sat behind
+//     the previous n-tile's stores in the in-order memory counter: five load -> wait -> store round trips per tile); ROLE 0 =
+//     everything, for the LeakyReLU network and other callers of the ABI.
 // SUBW: the packed weights are laid out for blocks of a.wpack_mtb 16-channel tiles (a wider BM); this block's BM channels are a
 // slice of one such group (the tail launches of dispatch_conv_deep's sub-batch split)
-template <int BM, int NT, bool LK = false, bool SUBW = false>
+template <int BM, int NT, bool LK = false, bool SUBW = false, int ROLE = 0, bool WRES = false>
 __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvArgs a, int total_tiles, int tiles_per_xcd)
 {
     using C = DeepCfg<BM, NT>;
     constexpr int MT = C::MT, MTB = C::MTB, PK = C::PK, WT = C::WT, HT = C::HT, GPP = C::GPP;
     constexpr int NIN = C::NIN, NW = C::NW, RIN = C::RIN, RW = C::RW, NS = C::NS;
+    constexpr bool R_FWD = ROLE == 1, R_BWD = ROLE == 2;
+    static_assert(!(WRES && SUBW), "resident weights: the kernel's own packing only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *in_tile = reinterpret_cast<bf16 *>(smem);
     bf16 *w_lds = in_tile + HT * WT * PK;
@@ -782,15 +853,15 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     const int tpi = tiles_x * tiles_y;
     const int group = blockIdx.y;
     const int nchunk = a.CIN / 32;
+    const int wchunks = WRES ? nchunk : 1;
 
     const int xcd = blockIdx.x & 7, nb = gridDim.x >> 3;
     const int t_begin = xcd * tiles_per_xcd;
     const int t_end = (t_begin + tiles_per_xcd < total_tiles) ? t_begin + tiles_per_xcd : total_tiles;
     int tile = t_begin + (blockIdx.x >> 3);
     if (tile >= t_end) return;
-    if (a.stagger > 0 && ((blockIdx.x >> 3) & 1))
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
 
+    constexpr int RWL = WRES ? 0 : RW;          // weight granules a thread prefetches per stage
     u32x4 rin[RIN], rw[RW];
     // Per lane and granule, once: position inside the halo tile.  Inside the loop an address is "uniform halo origin of the
     // tile (scalar unit) + 32-bit lane offset": a multiply-add, two compares and a pointer select per 16-byte load instead of a
@@ -806,57 +877,73 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
         g_c[i] = (g % GPP) * 8;
         g_pix[i] = (pix / WT) * a.W + pix % WT;       // pixel offset from the halo origin (row -1, column -1 of the tile)
     }
-    auto load_in = [&](int t, int chunk) {
+    // the stage a prefetch is for: wave-uniform, set once per stage
+    const bf16 *ld_base = nullptr;
+    int ld_xc = 0, ld_ty0 = 0, ld_tx0 = 0;
+    const u32x4 *ld_w = nullptr;
+    int ld_moff = 0;
+    auto set_stage = [&](int t, int chunk) {
         const int b = t / tpi, tr = t - b * tpi;
         const int tyi = tr / tiles_x;
-        const int tx0 = (tr - tyi * tiles_x) * C::TWD, ty0 = tyi * C::TH;
+        ld_tx0 = (tr - tyi * tiles_x) * C::TWD;
+        ld_ty0 = tyi * C::TH;
         const int c0 = chunk * 32;
         // a 32-channel chunk lies entirely in one of the two concatenated inputs
         const bool in1 = c0 < a.C1;
         const bf16 *xb = in1 ? a.x1 : a.x2;
-        const int xc = in1 ? a.C1 : a.C2, cb = in1 ? c0 : c0 - a.C1;
-        const long org = ((long)b * a.H + ty0 - 1) * a.W + tx0 - 1;            // halo origin pixel (may lie outside the image)
-        const bf16 *base = xb + org * xc + cb;
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            const bool ok = (unsigned)(ty0 + g_dy[i]) < (unsigned)a.H && (unsigned)(tx0 + g_dx[i]) < (unsigned)a.W;
-            const unsigned off = (unsigned)(g_pix[i] * xc + g_c[i]);
-            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(base + off) : &g_zero16;
-            rin[i] = *sp;
-        }
-    };
-    auto load_w = [&](int chunk) {
+        ld_xc = in1 ? a.C1 : a.C2;
+        const int cb = in1 ? c0 : c0 - a.C1;
+        const long org = ((long)b * a.H + ld_ty0 - 1) * a.W + ld_tx0 - 1;      // halo origin pixel (may lie outside the image)
+        ld_base = xb + org * ld_xc + cb;
         if constexpr (SUBW) {
             const int pm = a.wpack_mtb, per = pm / MTB;           // tiles per packed group, kernel groups per packed group
-            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)((group / per) * nchunk + chunk)) * NS * pm * 512);
-            const int m_off = (group % per) * MTB;
-#pragma unroll
-            for (int i = 0; i < RW; ++i) {
-                int g = tid + i * DEEP_THREADS;
-                g = g < NW ? g : NW - 1;
-                rw[i] = wsrc[((g / (MTB * 64)) * pm + m_off) * 64 + g % (MTB * 64)];
-            }
+            ld_w = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)((group / per) * nchunk + chunk)) * NS * pm * 512);
+            ld_moff = (group % per) * MTB;
         } else {
-            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NW * 8);
+            ld_w = reinterpret_cast<const u32x4 *>(a.wpack + ((size_t)(group * nchunk + chunk)) * NW * 8);
+        }
+    };
+    auto issue_in = [&](int i) {               // (i: a compile-time constant at every call)
+        const bool ok = (unsigned)(ld_ty0 + g_dy[i]) < (unsigned)a.H && (unsigned)(ld_tx0 + g_dx[i]) < (unsigned)a.W;
+        const unsigned off = (unsigned)(g_pix[i] * ld_xc + g_c[i]);
+        const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(ld_base + off) : &g_zero16;
+        rin[i] = *sp;
+    };
+    auto issue_w = [&](int i) {
+        int g = tid + i * DEEP_THREADS;
+        g = g < NW ? g : NW - 1;
+        if constexpr (SUBW) rw[i] = ld_w[((g / (MTB * 64)) * a.wpack_mtb + ld_moff) * 64 + g % (MTB * 64)];
+        else rw[i] = ld_w[g];
+    };
+    auto write_in = [&]() {
 #pragma unroll
-            for (int i = 0; i < RW; ++i) {
-                const int g = tid + i * DEEP_THREADS;
-                rw[i] = wsrc[g < NW ? g : NW - 1];
-            }
+        for (int i = 0; i < RIN; ++i) {
+            const int g = tid + i * DEEP_THREADS;
+            if (g < NIN) *reinterpret_cast<u32x4 *>(in_tile + (size_t)(g / GPP) * PK + (g % GPP) * 8) = rin[i];
+        }
+    };
+    auto write_w = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int g = tid + i * DEEP_THREADS;
+            if (g < NW) reinterpret_cast<u32x4 *>(w_lds + (size_t)slot * NW * 8)[g] = rw[i];
         }
     };
 
     // The bias of the block's channels sits in LDS behind the weights and is added in the epilogue (the accumulators
     // start from zero).  A global load of it per tile, issued behind the epilogue's stores, made the first MFMA of the next
     // tile wait for those stores to drain: loads and stores share one counter and complete out of order with each other.
-    float *bias_lds = reinterpret_cast<float *>(w_lds + (size_t)NW * 8);
+    // R_FWD: it is stored times the dropout's keep factor (the epilogue is one fma per value: acc * k + bias * k).
+    const DropoutParams dp = dropout_params(a.drop_p);
+    float *bias_lds = reinterpret_cast<float *>(w_lds + (size_t)wchunks * NW * 8);
     if (tid < BM) {
         int c = group * BM + tid;
         if constexpr (SUBW) {      // the block's channels are a strided slice of the packed group: 4 MT per lane group (see the epilogue)
             const int pm = a.wpack_mtb, per = pm / MTB, m_off = (group % per) * MTB;
             c = (group / per) * (pm * 16) + (m_off / 4) * 64 + 16 * (tid / (4 * MT)) + 4 * (m_off % 4) + tid % (4 * MT);
         }
-        bias_lds[tid] = (a.bias && c < a.COUT) ? a.bias[c] : 0.f;
+        const float bz = (a.bias && c < a.COUT) ? a.bias[c] : 0.f;
+        bias_lds[tid] = R_FWD ? bz * dp.inv_keep : bz;
     }
     f32x4 acc[MT][NT];
     auto reset_acc = [&]() {
@@ -867,50 +954,56 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
     };
     reset_acc();
 
-    const DropoutParams dp = dropout_params(a.drop_p);
     constexpr bool lk = LK;                 // LeakyReLU variant of the network (a.slope > 0)
     // fragment addresses that do not depend on the stage
     const bf16 *b_base = in_tile + ((size_t)(wn * WT + (lane & 15))) * PK + 8 * (lane >> 4);
-    const bf16 *a_base = w_lds + ((size_t)(wm * MT) * 64 + lane) * 8;
+    const bf16 *a_base0 = w_lds + ((size_t)(wm * MT) * 64 + lane) * 8;
 
-    // registers of a loaded stage -> LDS
-    auto write_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < RIN; ++i) {
-            const int g = tid + i * DEEP_THREADS;
-            if (g < NIN) *reinterpret_cast<u32x4 *>(in_tile + (size_t)(g / GPP) * PK + (g % GPP) * 8) = rin[i];
-        }
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const int g = tid + i * DEEP_THREADS;
-            if (g < NW) reinterpret_cast<u32x4 *>(w_lds)[g] = rw[i];
-        }
-    };
-    // The first stage goes into LDS in front of the loop, every later one at the loop's END.  With the LDS write at the loop's
-    // head (rounds 1-4) the head merged two states of the memory counter: the prologue's outstanding loads, and -- on the back
-    // edge -- the epilogue's outstanding STORES.  hipcc covered the first with s_waitcnt vmcnt(10) ... vmcnt(0) in front of the
-    // ds_writes, and since loads and stores share that counter the same waits made every block drain its output stores right
-    // behind issuing them, with the matrix cores idle and every CU of the chip doing so at the same moment: the "epilogue phase"
-    // that the round-4 ablations priced at 18-34 us per launch was that drain (an HBM write burst), not the epilogue's own
-    // instructions.  Here the loop head sees no outstanding load on either edge; the stores drain beside the next stage's MFMAs
-    // and are waited for only by that stage's end-of-loop delivery of its prefetch (in-order counter), a whole MFMA phase later.
     int chunk = 0;
-    load_in(tile, 0);
-    load_w(0);
-    write_stage();
+#ifdef MMK_DEEP_STAMPS
+    unsigned long long *stamp_lds = reinterpret_cast<unsigned long long *>(smem + (C::smem_core(wchunks) + 15) / 16 * 16);
+    int stamp_stage = 0;
+    for (int i = tid; i < 8 * MMK_STAMP_STAGES * 8; i += DEEP_THREADS) stamp_lds[i] = 0ull;
+#endif
+    // ---- prologue: the first stage (and, WRES, every chunk's weights) into LDS in front of the loop.  (Every later stage is
+    // written at the loop's END: a write at the loop's head would merge the prologue's outstanding loads with the back edge's
+    // outstanding epilogue stores in hipcc's counter bookkeeping, and the waits it then puts in front of the ds_writes make every
+    // block drain its own output stores right behind issuing them.)
+    if constexpr (WRES) {
+        for (int ck = 0; ck < nchunk; ++ck) {
+            set_stage(tile, ck);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) issue_w(i);
+            write_w(ck);
+        }
+    }
+    set_stage(tile, 0);
+#pragma unroll
+    for (int i = 0; i < RIN; ++i) issue_in(i);
+    if constexpr (!WRES) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) issue_w(i);
+        write_w(0);
+    }
+    write_in();
     __syncthreads();
+
+    constexpr int NCH = 4 * MT;                              // the lane's consecutive output channels per pixel
+    constexpr int LW = NCH >= 8 ? 8 : 4;                     // channels per operand load / store (16 or 8 bytes)
+    typedef __attribute__((ext_vector_type(LW))) __bf16 bfl;
+    constexpr int NP = NCH / LW;
+
     while (true) {
+        MMK_STAMP(0);
         int ntile = tile, nck = chunk + 1;
         if (nck == nchunk) {
             nck = 0;
             ntile = tile + nb;
         }
         const bool has_next = ntile < t_end;
-        {
-            const int lt = has_next ? ntile : tile;     // (clamped: the loads stay unconditional)
-            load_in(lt, nck);
-            load_w(nck);
-        }
+        set_stage(has_next ? ntile : tile, nck);     // (clamped: the loads stay unconditional)
+        const bf16 *a_base = a_base0 + (WRES ? (size_t)chunk * NW * 8 : (size_t)0);
+        MMK_STAMP(1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int ty = s / 3, tx = s % 3;
@@ -924,135 +1017,255 @@ __global__ __launch_bounds__(DEEP_THREADS) void conv3x3_deep_kernel(const ConvAr
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[n], acc[m][n], 0, 0, 0);
             }
+            // this tap's share of the next stage's prefetch: loads s and s + 9 of the thread's RIN + RWL
+#pragma unroll
+            for (int j = s; j < RIN + RWL; j += NS) {
+                if (j < RIN) issue_in(j);
+                else issue_w(j - RIN);
+            }
+            __builtin_amdgcn_sched_barrier(0x38F);       // everything but vector-memory instructions may be scheduled across
         }
-        // The prefetched stage has had the whole MFMA loop to arrive: take delivery of it HERE, in front of the epilogue's
-        // stores.  Left to the top of the next stage, the wait for these loads is a wait for "everything", i.e. for the
-        // stores to drain, with the matrix cores idle (loads and stores share vmcnt and complete out of order).
+        MMK_STAMP(2);
+        // Order of a tile's last stage: MFMA loop -> epilogue (its stores issued) -> delivery of the prefetch -> barrier -> LDS write
+        // -> barrier.  The prefetch loads are OLDER than the stores in the in-order memory counter, so their delivery is a counted
+        // wait that leaves the stores in flight (straight-line stores: hipcc knows the count); the stores then have the two
+        // barriers and the LDS write to complete before the next stage overwrites the registers they read (a store reads its data
+        // and address registers when the memory pipeline takes it, and hipcc makes the next writer of such a register wait for
+        // the store to complete).
+        auto deliver_and_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < RIN; ++i) asm volatile("" : "+v"(rin[i]));
+            for (int i = 0; i < RIN; ++i) asm volatile("" : "+v"(rin[i]));
 #pragma unroll
-        for (int i = 0; i < RW; ++i) asm volatile("" : "+v"(rw[i]));
-        if (chunk == nchunk - 1) {
+            for (int i = 0; i < RWL; ++i) asm volatile("" : "+v"(rw[i]));
+            MMK_STAMP(4);
+            if (has_next) {
+                __syncthreads();          // every wave is done reading this stage's fragments
+                MMK_STAMP(5);
+                write_in();
+                if constexpr (!WRES) write_w(0);
+            }
+            MMK_STAMP(6);
+        };
+        if (chunk != nchunk - 1) {
+            MMK_STAMP(3);
+            deliver_and_write();
+        } else {
+            // ---- per-lane output addressing of this tile.  The weights are packed so that the lane's 4 rows of each of its MT
+            // tiles are NCH = 4 MT consecutive output channels (pack_conv_weight_elem): tile m, register r = channel c0 + 4 m + r.
+            // The lane therefore stores -- and reads its ReLU source / accumulate target as -- one contiguous run of 2 NCH bytes
+            // per pixel, with no lane exchange.
             const int b = tile / tpi, tr = tile - b * tpi;
             const int tyi = tr / tiles_x;
             const int tx0 = (tr - tyi * tiles_x) * C::TWD, yy = tyi * C::TH + wn;
-            // The weights are packed so that the lane's 4 rows of each of its MT tiles are NCH = 4 MT consecutive output channels
-            // (pack_conv_weight_elem): tile m, register r = channel c0 + 4 m + r.  The lane therefore stores -- and reads its
-            // ReLU source / accumulate target as -- one contiguous run of 2 NCH bytes per pixel (two 16-byte pieces at 64 channels
-            // per wave), with no lane exchange: rounds 1-3 traded lane bits for tile bits with v_permlane16_swap here, which with
-            // its hazard padding and register copies was a third of the epilogue's ~1 500 instructions per tile (round 4: the
-            // epilogue alone is 16-24 us of a 60-GFLOP launch, profiles/r04_conv_dx_ablation_*.txt).
-            // (the lane index behind an opaque asm: the per-lane output pointers are derived here, once per tile,
-            // instead of living in registers across the MFMA loop)
             int lv = lane;
-            asm volatile("" : "+v"(lv));
-            constexpr int NCH = 4 * MT;
+            asm volatile("" : "+v"(lv));        // (derived here, once per tile, instead of living in registers across the MFMA loop)
             const int g4 = lv >> 4;
-            int c0;                                          // first of the lane's NCH channels
-            int bias_at;                                     // ... and where their bias sits in bias_lds
+            int c0, e_bias_at;                               // first of the lane's NCH channels, and where their bias sits
             if constexpr (SUBW) {
                 const int pm = a.wpack_mtb, per = pm / MTB, m_off = (group % per) * MTB;
                 c0 = (group / per) * (pm * 16) + (m_off / 4) * 64 + 16 * g4 + 4 * (m_off % 4);
-                bias_at = NCH * g4;
+                e_bias_at = NCH * g4;
             } else {
                 c0 = group * BM + wm * (16 * MT) + NCH * g4;
-                bias_at = wm * (16 * MT) + NCH * g4;
+                e_bias_at = wm * (16 * MT) + NCH * g4;
             }
-            if (c0 < a.COUT) {
-                const bool firstp = c0 < a.o1.C;
-                bf16 *const o_y = firstp ? a.o1.y : a.o2.y;
-                const bf16 *const o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
-                const int o_C = firstp ? a.o1.C : a.o2.C;
-                const bool o_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
-                const float o_scale = firstp ? a.o1.scale : a.o2.scale;
-                const int cl = firstp ? c0 : c0 - a.o1.C;
-                float bv[NCH];
-#pragma unroll
-                for (int k = 0; k < NCH; k += 4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(bias_lds + bias_at + k);
-                    bv[k] = t[0]; bv[k + 1] = t[1]; bv[k + 2] = t[2]; bv[k + 3] = t[3];
-                }
-                const int x0 = tx0 + (lv & 15);
-                const long p0 = ((long)b * a.H + yy) * a.W + x0;                 // the lane's pixel of n-tile 0
-                const unsigned e0 = (unsigned)p0 * (unsigned)a.COUT + (unsigned)c0 + a.hash_base;       // dropout element index
-                const unsigned e_step = 16u * (unsigned)a.COUT;
-                bf16 *const y0 = o_y + p0 * o_C + cl;
-                const bf16 *const s0 = o_src ? o_src + p0 * o_C + cl : nullptr;
-                const int step = 16 * o_C;                                        // elements between the pixels of consecutive n-tiles
-                const bool row_ok = yy < a.H;
+            const bool e_on = c0 < a.COUT;
+            const bool firstp = c0 < a.o1.C;
+            bf16 *const o_y = firstp ? a.o1.y : a.o2.y;
+            const bf16 *const o_src = firstp ? a.o1.relu_src : a.o2.relu_src;
+            const int o_C = firstp ? a.o1.C : a.o2.C;
+            const bool e_acc = (firstp ? a.o1.accumulate : a.o2.accumulate) != 0;
+            const float e_scale = firstp ? a.o1.scale : a.o2.scale;
+            const int cl = firstp ? c0 : c0 - a.o1.C;
+            const int e_x0 = tx0 + (lv & 15);
+            const long p0 = ((long)b * a.H + yy) * a.W + e_x0;                 // the lane's pixel of n-tile 0
+            const unsigned e_e0 = (unsigned)p0 * (unsigned)a.COUT + (unsigned)c0 + a.hash_base;       // dropout element index
+            bf16 *const e_y0 = o_y + p0 * o_C + cl;
+            const int e_step = 16 * o_C;                                        // elements between the pixels of consecutive n-tiles
+            const bool e_row_ok = yy < a.H;
+            const bool e_src = o_src != nullptr;
+            const bf16 *const e_pf0 = e_src ? o_src + p0 * o_C + cl : (e_acc ? (const bf16 *)e_y0 : nullptr);
+            // the epilogue's operands (ReLU source, or accumulate target) of ALL n-tiles in front of the first store.  Every slot is
+            // written (lanes without an operand read zeros): nothing of it is live outside this branch.
+            bfl opnd[R_BWD ? NT : 1][NP];
+            auto fetch_operands = [&]() {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const bool okp = row_ok && x0 + n * 16 < a.W;
-                    float v[NCH];
+                    const bool okp = e_on && e_pf0 != nullptr && e_row_ok && e_x0 + n * 16 < a.W;
+                    const bf16 *pp = okp ? e_pf0 + n * e_step : reinterpret_cast<const bf16 *>(g_zero32);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int k = 0; k < NP; ++k) opnd[R_BWD ? n : 0][k] = *reinterpret_cast<const bfl *>(pp + k * LW);
+                }
+            };
+            if constexpr (R_BWD) fetch_operands();
+            if (e_on) {
+                if constexpr (R_FWD) {
+                    // ---- forward: y = dropout(relu(acc + bias)) as packed bf16 pairs
+                    float bk[NCH];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float t = acc[m][n][r] + bv[4 * m + r];
-                            if (a.relu) t = lk ? act_leaky(t, a.slope) : fmaxf(t, 0.f);
-                            v[4 * m + r] = t;
-                        }
-                    if (a.drop_p > 0.f) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            float sc[4];
-                            dropout_scale4(a.seed, e0 + (unsigned)n * e_step + 4u * m, dp, sc);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[4 * m + r] = lk ? drop_leaky(v[4 * m + r], sc[r]) : v[4 * m + r] * sc[r];
-                        }
+                    for (int k = 0; k < NCH; k += 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4 *>(bias_lds + e_bias_at + k);
+                        bk[k] = t[0]; bk[k + 1] = t[1]; bk[k + 2] = t[2]; bk[k + 3] = t[3];
                     }
-                    bf16 *const dst = y0 + n * step;
-                    constexpr int LW = NCH >= 8 ? 8 : 4;                 // channels per operand load (16 or 8 bytes)
-                    typedef __attribute__((ext_vector_type(LW))) __bf16 bfl;
-                    if (o_src && okp) {
-                        const bf16 *sp = s0 + n * step;
+                    const float kf = dp.inv_keep;
+                    // keep <=> (signed 16-bit draw) >= thr - 32768: (thr - 32768 - 1) - draw, saturating, is negative exactly then
+                    // (thr = 0, no dropout: the subtrahend saturates at -32768, which the no-dropout draws of +32767 pass)
+                    const int t1s = (int)dp.thr - 32768 - 1;
+                    const unsigned t1 = (unsigned)(t1s < -32768 ? -32768 : t1s) & 0xffffu;
+                    const unsigned thr1 = t1 | (t1 << 16);
+                    const bool drop = a.drop_p > 0.f;
 #pragma unroll
-                        for (int k = 0; k < NCH; k += LW) {
-                            const bfl sv = *reinterpret_cast<const bfl *>(sp + k);
+                    for (int n = 0; n < NT; ++n) {
+                        const bool okp = e_row_ok && e_x0 + n * 16 < a.W;
+                        // the hash words of the n-tile's MT channel groups; without dropout: draws of +32767, which every
+                        // threshold keeps (one scalar branch per n-tile)
+                        unsigned hw[MT][2];
 #pragma unroll
-                            for (int r = 0; r < LW; ++r)
-                                v[k + r] = lk ? v[k + r] * bwd_factor_leaky((float)sv[r], o_scale, a.slope)
-                                              : (((float)sv[r] > 0.f) ? v[k + r] * o_scale : 0.f);
+                        for (int m = 0; m < MT; ++m) hw[m][0] = hw[m][1] = 0x7fff7fffu;
+                        if (drop) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                dropout_words(a.seed, e_e0 + (unsigned)n * (16u * (unsigned)a.COUT) + 4u * m, hw[m][0], hw[m][1]);
                         }
-                    }
-                    if (o_acc && okp) {
+                        unsigned pk[NCH / 2];
 #pragma unroll
-                        for (int k = 0; k < NCH; k += LW) {
-                            const bfl ov = *reinterpret_cast<const bfl *>(dst + k);
+                        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                            for (int r = 0; r < LW; ++r) v[k + r] += (float)ov[r];
-                        }
-                    }
-                    if (okp) {
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                const float t0 = __builtin_fmaf(acc[m][n][2 * hlf], kf, bk[4 * m + 2 * hlf]);
+                                const float t1f = __builtin_fmaf(acc[m][n][2 * hlf + 1], kf, bk[4 * m + 2 * hlf + 1]);
+                                pk[2 * m + hlf] = pk_relu_bf16(cvt_pk_bf16(t0, t1f)) & pk_keep_mask(hw[m][hlf], thr1);
+                            }
+                        // (unconditional, straight-line stores: pixels outside the image go to a sink)
+                        bf16 *const dst = okp ? e_y0 + n * e_step : reinterpret_cast<bf16 *>(g_sink32);
                         if constexpr (NCH >= 8) {
 #pragma unroll
-                            for (int k = 0; k < NCH; k += 8) {
-                                bf16x8 o8;
+                            for (int k = 0; k < NCH / 2; k += 4)
+                                *reinterpret_cast<u32x4 *>(dst + 2 * k) = (u32x4){pk[k], pk[k + 1], pk[k + 2], pk[k + 3]};
+                        } else {
+                            *reinterpret_cast<unsigned long long *>(dst) = ((unsigned long long)pk[1] << 32) | pk[0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);     // one n-tile at a time: bounds the live temporaries
+                    }
+                } else {
+                    // ---- data gradient (R_BWD) / generic epilogue
+                    float bv[NCH];
+                    if constexpr (!R_BWD) {
 #pragma unroll
-                                for (int r = 0; r < 8; ++r) o8[r] = (bf16)v[k + r];
-                                *reinterpret_cast<bf16x8 *>(dst + k) = o8;
+                        for (int k = 0; k < NCH; k += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4 *>(bias_lds + e_bias_at + k);
+                            bv[k] = t[0]; bv[k + 1] = t[1]; bv[k + 2] = t[2]; bv[k + 3] = t[3];
+                        }
+                    }
+                    const bool o_accf = !e_src && e_acc;            // R_BWD: the operand slots hold the accumulate target
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bool okp = e_row_ok && e_x0 + n * 16 < a.W;
+                        float v[NCH];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float t = acc[m][n][r];
+                                if constexpr (!R_BWD) {
+                                    t += bv[4 * m + r];
+                                    if (a.relu) t = lk ? act_leaky(t, a.slope) : fmaxf(t, 0.f);
+                                }
+                                v[4 * m + r] = t;
+                            }
+                        if constexpr (!R_BWD) {
+                            if (a.drop_p > 0.f) {
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) {
+                                    float sc[4];
+                                    dropout_scale4(a.seed, e_e0 + (unsigned)n * (16u * (unsigned)a.COUT) + 4u * m, dp, sc);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[4 * m + r] = lk ? drop_leaky(v[4 * m + r], sc[r]) : v[4 * m + r] * sc[r];
+                                }
+                            }
+                        }
+                        bf16 *const dst0 = e_y0 + n * e_step;
+                        if constexpr (R_BWD) {
+                            if (e_pf0 != nullptr && okp) {
+                                if (!o_accf) {
+#pragma unroll
+                                    for (int k = 0; k < NCH; k += LW) {
+                                        const bfl sv = opnd[n][k / LW];
+#pragma unroll
+                                        for (int r = 0; r < LW; ++r) v[k + r] = ((float)sv[r] > 0.f) ? v[k + r] * e_scale : 0.f;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < NCH; k += LW) {
+                                        const bfl ov = opnd[n][k / LW];
+#pragma unroll
+                                        for (int r = 0; r < LW; ++r) v[k + r] += (float)ov[r];
+                                    }
+                                }
                             }
                         } else {
-                            bf16x4 o4;
+                            if (e_src && okp) {
+                                const bf16 *sp = e_pf0 + n * e_step;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o4[r] = (bf16)v[r];
-                            *reinterpret_cast<bf16x4 *>(dst) = o4;
+                                for (int k = 0; k < NCH; k += LW) {
+                                    const bfl sv = *reinterpret_cast<const bfl *>(sp + k);
+#pragma unroll
+                                    for (int r = 0; r < LW; ++r)
+                                        v[k + r] = lk ? v[k + r] * bwd_factor_leaky((float)sv[r], e_scale, a.slope)
+                                                      : (((float)sv[r] > 0.f) ? v[k + r] * e_scale : 0.f);
+                                }
+                            }
+                            if (e_acc && okp) {
+#pragma unroll
+                                for (int k = 0; k < NCH; k += LW) {
+                                    const bfl ov = *reinterpret_cast<const bfl *>(dst0 + k);
+#pragma unroll
+                                    for (int r = 0; r < LW; ++r) v[k + r] += (float)ov[r];
+                                }
+                            }
+                        }
+                        if (R_BWD || okp) {
+                            bf16 *const dst = (R_BWD && !okp) ? reinterpret_cast<bf16 *>(g_sink32) : dst0;
+                            if constexpr (NCH >= 8) {
+#pragma unroll
+                                for (int k = 0; k < NCH; k += 8) {
+                                    bf16x8 o8;
+#pragma unroll
+                                    for (int r = 0; r < 8; ++r) o8[r] = (bf16)v[k + r];
+                                    *reinterpret_cast<bf16x8 *>(dst + k) = o8;
+                                }
+                            } else {
+                                bf16x4 o4;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o4[r] = (bf16)v[r];
+                                *reinterpret_cast<bf16x4 *>(dst) = o4;
+                            }
                         }
                     }
                 }
             }
             reset_acc();
+            MMK_STAMP(3);
+            deliver_and_write();
         }
         if (!has_next) break;
-        __syncthreads();          // every wave is done reading this stage's fragments
-        write_stage();
         __syncthreads();
+        MMK_STAMP(7);
+#ifdef MMK_DEEP_STAMPS
+        ++stamp_stage;
+#endif
         tile = ntile;
         chunk = nck;
     }
+#ifdef MMK_DEEP_STAMPS
+    __syncthreads();
+    if (g_deep_stamp_buf != nullptr && blockIdx.y == 0 && blockIdx.x < 64)
+        for (int i = tid; i < 8 * MMK_STAMP_STAGES * 8; i += DEEP_THREADS)
+            g_deep_stamp_buf[(size_t)blockIdx.x * (8 * MMK_STAMP_STAGES * 8) + i] = stamp_lds[i];
+#endif
 }
 
-template <int BM, int NT, bool LK = false, bool SUBW = false>
+template <int BM, int NT, bool LK = false, bool SUBW = false, int ROLE = 0, bool WRES = false>
 int launch_conv_deep(const ConvArgs &a, hipStream_t st)
 {
     using C = DeepCfg<BM, NT>;
@@ -1060,26 +1273,26 @@ int launch_conv_deep(const ConvArgs &a, hipStream_t st)
     int dev = 0;
     MMK_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
-        if (C::SMEM > 64 * 1024)
-            MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT, LK, SUBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)C::SMEM));
+        MMK_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_deep_kernel<BM, NT, LK, SUBW, ROLE, WRES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
+    const size_t smem = C::smem(WRES ? a.CIN / 32 : 1);
+    MMK_REQUIRE(smem <= (size_t)160 * 1024, "mmk_conv3x3: %zu bytes of LDS for CIN=%d COUT=%d", smem, a.CIN, a.COUT);
     const int tiles = ((a.W + C::TWD - 1) / C::TWD) * ((a.H + C::TH - 1) / C::TH);
     const int groups = (a.COUT + BM - 1) / BM;
     const int total = tiles * a.B;
     const int per_xcd = (total + 7) / 8;
     int nb = 32 / groups;                                    // one 8-wave block per CU, 32 CUs per XCD
     nb = nb < 1 ? 1 : (nb > per_xcd ? per_xcd : nb);
-    ConvArgs b = a;
-    {
-        const char *e = getenv("MMK_DEEP_STAGGER");        // experiment switch (read per call)
-        if (e) b.stagger = atoi(e);
-    }
-    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK, SUBW>), dim3(8 * nb, groups), dim3(DEEP_THREADS), C::SMEM, st, b, total, per_xcd);
+    hipLaunchKernelGGL((conv3x3_deep_kernel<BM, NT, LK, SUBW, ROLE, WRES>), dim3(8 * nb, groups), dim3(DEEP_THREADS), smem, st, a, total, per_xcd);
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }
+
+// the packed weights of every input-channel chunk stay in LDS beside the halo tile (conv3x3_deep_kernel: WRES)
+template <int BM, int NT>
+bool deep_weights_fit(int cin) { return DeepCfg<BM, NT>::smem(cin / 32) <= (size_t)160 * 1024; }
 
 // Rounds of tiles the persistent grid of the plain launch walks (one 8-wave block per CU): blocks of an XCD share its
 // contiguous range of tiles.
@@ -1138,7 +1351,7 @@ int dispatch_conv_deep(const ConvArgs &a, hipStream_t st)
             adv(t.o2);
             t.hash_base = a.hash_base + (unsigned)(px * a.COUT);
             t.wpack_mtb = BM / 16;
-            return narrow ? launch_conv_deep<32, 3, false, true>(t, st) : launch_conv_deep<32, 5, false, true>(t, st);
+            return narrow ? launch_conv_deep<32, 3, false, true, 1>(t, st) : launch_conv_deep<32, 5, false, true, 1>(t, st);
         }
     }
     return dispatch_conv_deep_plain(a, st);
@@ -1153,6 +1366,22 @@ int dispatch_conv_deep_plain(const ConvArgs &a, hipStream_t st)
         MMK_DEEP_CASE(16); MMK_DEEP_CASE(32); MMK_DEEP_CASE(64); MMK_DEEP_CASE(128);
 #undef MMK_DEEP_CASE
     }
+    // the epilogue's role (conv3x3_deep_kernel: ROLE): forward = activation, no epilogue operand; backward = no bias / activation /
+    // dropout and at most ONE operand kind (ReLU source or accumulate target) per output half; anything else: the generic kernel
+    const bool any_src = a.o1.relu_src != nullptr || (a.o2.C > 0 && a.o2.relu_src != nullptr);
+    const bool any_acc = a.o1.accumulate != 0 || (a.o2.C > 0 && a.o2.accumulate != 0);
+    const bool both1 = a.o1.relu_src != nullptr && a.o1.accumulate != 0, both2 = a.o2.C > 0 && a.o2.relu_src != nullptr && a.o2.accumulate != 0;
+    const int role = (a.relu != 0 && !any_src && !any_acc) ? 1
+                   : ((a.relu == 0 && a.bias == nullptr && a.drop_p == 0.f && !both1 && !both2) ? 2 : 0);
+#define MMK_DEEP_CASE(M, R)                                                                                                        \
+    if (BM == M && role == R) {                                                                                                    \
+        if (M <= 64 && a.wpack_mtb == 0 && (narrow ? deep_weights_fit<M, 3>(a.CIN) : deep_weights_fit<M, 5>(a.CIN)))               \
+            return narrow ? launch_conv_deep<M, 3, false, false, R, (M <= 64)>(a, st) : launch_conv_deep<M, 5, false, false, R, (M <= 64)>(a, st); \
+        return narrow ? launch_conv_deep<M, 3, false, false, R>(a, st) : launch_conv_deep<M, 5, false, false, R>(a, st);              \
+    }
+    MMK_DEEP_CASE(32, 1); MMK_DEEP_CASE(64, 1); MMK_DEEP_CASE(128, 1);
+    MMK_DEEP_CASE(32, 2); MMK_DEEP_CASE(64, 2); MMK_DEEP_CASE(128, 2);
+#undef MMK_DEEP_CASE
 #define MMK_DEEP_CASE(M) if (BM == M) return narrow ? launch_conv_deep<M, 3>(a, st) : launch_conv_deep<M, 5>(a, st)
     MMK_DEEP_CASE(16); MMK_DEEP_CASE(32); MMK_DEEP_CASE(64); MMK_DEEP_CASE(128);
 #undef MMK_DEEP_CASE
@@ -3326,6 +3555,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16 *__restric
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
 
 }  // namespace
+
+#ifdef MMK_DEEP_STAMPS
+extern "C" int mmk_debug_deep_stamps(unsigned long long *buf)
+{
+    MMK_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamp_buf), &buf, sizeof(buf)));
+    return MMK_OK;
+}
+#endif
 
 // ================================================================================== C ABI
 extern "C" size_t mmk_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t transposed)

@@ -51,8 +51,9 @@ struct ConvArgs {
 // WHICH elements are dropped -- the backward kernels read the mask back from the stored activation -- only on the rate and
 // on independence (scripts/dropout_hash_check.py; the chain itself: below).
 struct DropoutParams {
-    unsigned thr;      // drop when the 16-bit draw is below thr
+    unsigned thr;      // drop probability thr / 65536: an element is kept when its SIGNED 16-bit draw is >= thr - 32768
     float inv_keep;    // 1 / (1 - thr / 65536): exactly unbiased for the quantised probability
+    int thr_s;         // thr - 32768
 };
 
 __host__ __device__ inline DropoutParams dropout_params(float p)
@@ -60,6 +61,7 @@ __host__ __device__ inline DropoutParams dropout_params(float p)
     DropoutParams d;
     d.thr = (unsigned)(p * 65536.0f + 0.5f);
     d.inv_keep = d.thr ? 65536.0f / (float)(65536u - d.thr) : 1.0f;
+    d.thr_s = (int)d.thr - 32768;
     return d;
 }
 
@@ -70,37 +72,47 @@ __host__ __device__ inline DropoutParams dropout_params(float p)
 // EVEN C -- same instruction count, same full-rate pipe.  scripts/dropout_hash_check.py on 2^25 groups: all quadruples distinct,
 // byte histograms at chi^2 / dof = 1.0, |correlation| <= 5e-4 within a group, between neighbours and between the masks of
 // consecutive layer seeds.
-__device__ __forceinline__ void dropout_draws4(unsigned seed, unsigned e4, unsigned (&d)[4])
+// the two hash words of the group of 4 consecutive channels starting at element index e4: their four 16-bit halves are the draws
+__device__ __forceinline__ void dropout_words(unsigned seed, unsigned e4, unsigned &h, unsigned &g)
 {
     const unsigned i = e4 >> 2;                       // group number
-    unsigned h = __umul24(i, 0x9E3779u) + (seed + (i & 0xff000000u));
+    h = __umul24(i, 0x9E3779u) + (seed + (i & 0xff000000u));
     h ^= h >> 13;
     h = __umul24(h, 0x85EBCAu) + h;
     h ^= h >> 11;
     h = __umul24(h, 0xC2B2AEu) + h;
     h ^= h >> 15;
-    unsigned g = h ^ 0x85ebca6bU;
+    g = h ^ 0x85ebca6bU;
     g ^= g >> 12;
     g = __umul24(g, 0x7FEB34u) + g;
     g ^= g >> 14;
-    d[0] = h & 0xffffu; d[1] = h >> 16; d[2] = g & 0xffffu; d[3] = g >> 16;
+}
+
+// ... as signed 16-bit integers (element r of the group: low / high half of h, low / high half of g).  Signed, so that a kernel
+// can form the keep masks of two values at once on the packed halves (saturating v_pk_sub_i16 + arithmetic shift); every
+// kernel of the library uses the same rule: an element is kept when draw >= thr - 32768.
+__device__ __forceinline__ void dropout_draws4(unsigned seed, unsigned e4, int (&d)[4])
+{
+    unsigned h, g;
+    dropout_words(seed, e4, h, g);
+    d[0] = (int)(short)(h & 0xffffu); d[1] = (int)h >> 16; d[2] = (int)(short)(g & 0xffffu); d[3] = (int)g >> 16;
 }
 
 __device__ __forceinline__ void dropout_scale4(unsigned seed, unsigned e4, const DropoutParams &d, float (&sc)[4])
 {
-    unsigned dr[4];
+    int dr[4];
     dropout_draws4(seed, e4, dr);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[r] = (dr[r] >= d.thr) ? d.inv_keep : 0.f;
+    for (int r = 0; r < 4; ++r) sc[r] = (dr[r] >= d.thr_s) ? d.inv_keep : 0.f;
 }
 
 // the same draws as keep flags (the caller has folded the factor 1 / keep into the value already)
 __device__ __forceinline__ void dropout_keep4(unsigned seed, unsigned e4, const DropoutParams &d, bool (&keep)[4])
 {
-    unsigned dr[4];
+    int dr[4];
     dropout_draws4(seed, e4, dr);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) keep[r] = dr[r] >= d.thr;
+    for (int r = 0; r < 4; ++r) keep[r] = dr[r] >= d.thr_s;
 }
 
 }  // namespace mmku

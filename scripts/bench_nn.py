@@ -1,5 +1,4 @@
-"""Micro-benchmark of the stand-alone NN kernel at the bench shape (unseeded: no previous correspondents); MMK_NN_MFMA=0 runs
-the vector-pipe filter for comparison."""
+"""Micro-benchmark of the stand-alone NN kernel at the bench shape (unseeded: no previous correspondents)."""
 import ctypes, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,4 +30,4 @@ t = np.array(ms[:n.value]) * 1e3
 ir, dr = _clib.nn_search(src[:2, :, :dim].cpu().numpy(), np.ascontiguousarray(tgt[:2, :, :dim].cpu().numpy()))
 ok = np.array_equal(idx[:2].cpu().numpy(), ir) and np.array_equal(d2[:2].cpu().numpy(), dr)
 evals = B * N * Mpad
-print("%-18s dim %d: median %.1f us  min %.1f us  -> %.2f Tevals/s  bit-exact=%s" % (("vector-pipe filter" if (os.environ.get("MMK_NN_MFMA", "1") == "0" or dim == 3) else "matrix-core filter"), dim, np.median(t), t.min(), evals / np.median(t) / 1e6, ok), flush=True)
+print("%-18s dim %d: median %.1f us  min %.1f us  -> %.2f Tevals/s  bit-exact=%s" % ("matrix-core filter", dim, np.median(t), t.min(), evals / np.median(t) / 1e6, ok), flush=True)

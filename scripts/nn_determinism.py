@@ -1,5 +1,5 @@
 """dICP forward at the bench shape twice on identical inputs: correspondences of every iteration must be bit-identical run to
-run (and equal between NN engines: run once more with MMK_NN_MFMA=0 and compare the printed checksums)."""
+run (and equal between the brute-force and the grid engine)."""
 import os, sys, hashlib
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,7 @@
 rank), twice per set: prints, per set, a checksum of the correspondences of the rows that were active (pairs that have converged
 keep stale rows), the number of run-to-run differences, and the number of indices that sit on the clamp of
 icp_accumulate_kernel (index 0 / M - 1: an unarmed key would land there).  Run once per build / NN engine and diff the output:
-    MMK_LIB=... python scripts/nn_sweep.py > a.txt;  MMK_NN_MFMA=0 python scripts/nn_sweep.py > b.txt"""
+    MMK_LIB=... python scripts/nn_sweep.py > a.txt   (compare two builds through MMK_LIB)"""
 import os, sys, hashlib
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

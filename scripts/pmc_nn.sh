@@ -1,5 +1,5 @@
 # rocprofv3 --pmc passes over the dICP alone (scripts/prof_nn.py) for the NN kernel; run on the GPU box from the repo root:
-#   bash scripts/pmc_nn.sh <tag>     (MMK_NN_MFMA=0: the vector-pipe filter)
+#   bash scripts/pmc_nn.sh <tag>
 set -e
 tag=${1:-pf1}
 cd /tmp && export TMPDIR=/tmp
