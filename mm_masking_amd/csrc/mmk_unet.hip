@@ -25,6 +25,37 @@ namespace {
 
 using namespace mmku;       // shared with mmk_conv_dx.hip: element types, ConvArgs, the dropout hash (mmk_unet_shared.h)
 
+// Packed bf16 / int16 helpers of the forward epilogues.  (hipcc has no builtin for v_cvt_pk_bf16_f32 and turns the vector forms of
+// the other two into per-half compares and selects; one instruction per asm statement, so that hipcc pads and schedules around
+// each of them itself.)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned x)          // max(x, 0) on both halves' bit patterns (-0 -> +0)
+{
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max_i16(unsigned x, unsigned y)     // y = 0: ReLU; y = 0x80008000: identity
+{
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// 0xffff in the halves where the signed 16-bit draw of `words` is >= thr - 32768 (thr1pk = both halves thr - 32768 - 1)
+__device__ __forceinline__ unsigned pk_keep_mask(unsigned words, unsigned thr1pk)
+{
+    unsigned d, m;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(thr1pk), "v"(words));
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(0x000f000fu), "v"(d));
+    return m;
+}
+
+
 constexpr int TH = 8, TW = 32;            // output pixels per block tile
 constexpr int HT = TH + 2, WT = TW + 2;   // halo tile
 constexpr int CONV_THREADS = 256;
@@ -525,6 +556,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     const bool c8_has_src = a.o1.relu_src != nullptr, c8_accm = a.o1.accumulate != 0;
     const float c8_scale = a.o1.scale;
     const float relu_lo = a.relu ? 0.f : -INFINITY;           // v = max(v, relu_lo): ReLU or identity
+    const unsigned relu_pk = a.relu ? 0u : 0x80008000u;        // the same on packed bf16 bit patterns (v_pk_max_i16)
     // LDS read offsets of the B fragments: per-lane part (tap of the lane's k group) per k-step; the
     // N-tile part is an immediate
     int b_lane[NS];
@@ -621,6 +653,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     // the ReLU; dk = 1 without dropout, where the fma IS the addition), and the draws then only zero elements -- one
     // multiplication per output value less in kernels that are bound by vector-instruction issue.
     const float dk = a.drop_p > 0.f ? dp.inv_keep : 1.f;
+    // both halves thr - 32768 - 1: (that) - draw, saturating, is negative exactly for the draws that are kept (pk_keep_mask)
+    const unsigned thr1pk = ((unsigned)(dp.thr_s - 1 < -32768 ? -32768 : dp.thr_s - 1) & 0xffffu) * 0x00010001u;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -790,30 +824,6 @@ struct DeepCfg {
     static constexpr size_t smem(int wchunks) { return smem_core(wchunks); }
 #endif
 };
-
-// Packed bf16 / int16 helpers of the forward epilogue.  (hipcc has no builtin for v_cvt_pk_bf16_f32 and turns the vector forms of
-// the other two into per-half compares and selects; one instruction per asm statement, so that hipcc pads and schedules around
-// each of them itself.)
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
-{
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ unsigned pk_relu_bf16(unsigned x)          // max(x, 0) on both halves' bit patterns (-0 -> +0)
-{
-    unsigned r;
-    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(x));
-    return r;
-}
-// 0xffff in the halves where the signed 16-bit draw of `words` is >= thr - 32768 (thr1pk = both halves thr - 32768 - 1)
-__device__ __forceinline__ unsigned pk_keep_mask(unsigned words, unsigned thr1pk)
-{
-    unsigned d, m;
-    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(thr1pk), "v"(words));
-    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(0x000f000fu), "v"(d));
-    return m;
-}
 
 // Round 5.  What the round-4 kernel's stages spent their cycles on (s_memtime stamps of a diagnostic build, scripts/deep_stamps.py,
 // 64 -> 64 at 160 x 160; per stage of ~11 500 cycles, with an epilogue every second stage): issuing the 12 prefetch loads of a

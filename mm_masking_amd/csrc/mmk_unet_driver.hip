@@ -222,15 +222,8 @@ int side_stream(SideStream **out)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     SideStream &s = pool[dev & 15];
     if (s.st == nullptr || s.dev != dev) {
-        {
-            // experiment (round 5): MMK_SIDE_PRIO=1 creates the weight-gradient stream with the highest priority the device offers
-            const char *e = getenv("MMK_SIDE_PRIO");
-            int lo = 0, hi = 0;
-            if (e && e[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-                MMK_CHECK_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
-            else
-                MMK_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-        }
+        // (a highest-priority stream changes nothing: round 5, gpurun_out/r05_call8.txt)
+        MMK_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         MMK_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         MMK_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         s.dev = dev;

@@ -40,7 +40,6 @@ struct ConvArgs {
     // 16-channel tiles per group of the packing, 0 = the kernel's own width)
     unsigned hash_base = 0;
     int wpack_mtb = 0;
-    int stagger = 0;       // >= 64-channel kernel: every other block of an XCD starts this many 1 024-cycle sleeps late (de-phasing)
 };
 
 // Inverted-dropout scales (0 or 1/keep) of the 4 consecutive channels starting at element index e4 (a multiple of 4): four

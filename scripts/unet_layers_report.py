@@ -84,11 +84,30 @@ def main():
         a["hbm_read"] += e.get("hbm_read_bytes", 0.0); a["hbm_write"] += e.get("hbm_write_bytes", 0.0)
         c = e.get("counters", {})
         a["mfma_busy_cycles"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); a["gui_active"] += c.get("GRBM_GUI_ACTIVE", 0.0)
+        for nm in ("SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+                   "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"):
+            a[nm] = a.get(nm, 0.0) + c.get(nm, 0.0)
     busy, traf = [], []
     for k, a in cls.items():
         if a["flop"] > 0 and a["gui_active"] > 0:
-            busy.append({"kernel": k, "launches_per_pass": a["launches"], "us_per_pass": a["us"], "TFLOPs": a["flop"] / a["us"] * 1e-6,
-                         "mfma_busy_frac": a["mfma_busy_cycles"] / (1024.0 * a["gui_active"] / 8.0)})
+            ent = {"kernel": k, "launches_per_pass": a["launches"], "us_per_pass": a["us"], "TFLOPs": a["flop"] / a["us"] * 1e-6,
+                   "mfma_busy_frac": a["mfma_busy_cycles"] / (1024.0 * a["gui_active"] / 8.0)}
+            # round 5: overlap and LDS counters of the second SQ pass (absent when that pass did not run)
+            if a.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0.0) > 0 and a["mfma_busy_cycles"] > 0:
+                ent["valu_coexec_frac_of_mfma_busy"] = a["SQ_VALU_MFMA_COEXEC_CYCLES"] / a["mfma_busy_cycles"]
+            if a.get("SQ_LDS_IDX_ACTIVE", 0.0) > 0:
+                ent["lds_bank_conflict_frac"] = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"]
+                ent["lds_array_active_frac"] = a["SQ_LDS_IDX_ACTIVE"] / (256.0 * a["gui_active"] / 8.0)
+            if a.get("SQ_WAVE_CYCLES", 0.0) > 0:
+                ent["wave_cycles_waiting_frac"] = a.get("SQ_WAIT_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
+                ent["wave_cycles_issue_stalled_frac"] = a.get("SQ_WAIT_INST_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
+                if a.get("SQ_WAIT_INST_LDS", 0.0) > 0:
+                    ent["wave_cycles_lds_issue_stall_frac"] = a["SQ_WAIT_INST_LDS"] / a["SQ_WAVE_CYCLES"]
+            if a.get("SQ_INSTS_MFMA", 0.0) > 0:
+                ent["valu_insts_per_mfma"] = a.get("SQ_INSTS_VALU", 0.0) / a["SQ_INSTS_MFMA"]
+                if a.get("SQ_INSTS_LDS", 0.0) > 0:
+                    ent["lds_insts_per_mfma"] = a["SQ_INSTS_LDS"] / a["SQ_INSTS_MFMA"]
+            busy.append(ent)
         if a["alg_read"] + a["alg_write"] > 0:
             traf.append({"kernel": k, "launches_per_pass": a["launches"], "us_per_pass": a["us"],
                          "algorithmic_read_MB": a["alg_read"] / 1e6, "algorithmic_write_MB": a["alg_write"] / 1e6,
