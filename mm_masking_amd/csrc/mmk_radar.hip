@@ -111,6 +111,82 @@ __global__ __launch_bounds__(CFAR_T) void cfar_mask_kernel(const float *__restri
     for (int c = threadIdx.x; c < R; c += CFAR_T) mask[base + c] = cell(c);
 }
 
+// The same, persistent (round 5): a block walks rows blockIdx.x, + gridDim.x, ... and holds the NEXT row in registers while it
+// scans / thresholds / stores the current one from LDS, so that no row's HBM latency is exposed (the one-row-per-block form is a
+// load -> scan -> compute -> store latency chain end to end, at four rows in flight per CU).  Same thread -> cell partition and
+// the same fp64 sums as cfar_mask_kernel: bit-identical masks.  NPRE >= ceil(R / CFAR_T).
+template <int NPRE>
+__global__ __launch_bounds__(CFAR_T) void cfar_mask_rows_kernel(const float *__restrict__ raw, int rows, int R, int w2, int guard,
+                                                                int mincol, int maxcol, float a_th, float b_th, int diff,
+                                                                float steep, float *__restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *cs = reinterpret_cast<double *>(smem);                 // R + 1
+    float *row = reinterpret_cast<float *>(cs + (R + 1));          // R
+    __shared__ double wsum[CFAR_T / 64];
+    float nx[NPRE];
+    int r = blockIdx.x;
+    if (r >= rows) return;
+    auto fetch = [&](int rr) {
+        const float *src = raw + (size_t)rr * R;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int c = threadIdx.x + i * CFAR_T;
+            nx[i] = src[c < R ? c : R - 1];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int c = threadIdx.x + i * CFAR_T;
+            if (c < R) row[c] = nx[i];
+        }
+    };
+    fetch(r);
+    stage();
+    __syncthreads();
+    const int L = (R + CFAR_T - 1) / CFAR_T;
+    const int c0 = min(R, (int)threadIdx.x * L), c1 = min(R, c0 + L);
+    while (true) {
+        const int rn = r + gridDim.x;
+        fetch(rn < rows ? rn : r);                                  // (unconditional: past the last row the current one again)
+        double s = 0.0;
+        for (int c = c0; c < c1; ++c) s += (double)row[c];
+        double tot;
+        double run = block_excl_scan<CFAR_T>(s, wsum, &tot);
+        for (int c = c0; c < c1; ++c) {
+            cs[c] = run;
+            run += (double)row[c];
+        }
+        if (threadIdx.x == CFAR_T - 1) cs[R] = tot;
+        __syncthreads();
+        float *out = mask + (size_t)r * R;
+        for (int c = threadIdx.x; c < R; c += CFAR_T) {
+            float th = 1000.0f;
+            if (c >= mincol && c < maxcol) {
+                const float left = (float)(cs[c - guard] - cs[c - w2 - guard]);
+                const float right = (float)(cs[min(R, c + w2 + guard + 1)] - cs[min(R, c + guard + 1)]);
+                const float stat = fmaxf(left, right) / (float)w2;
+                th = a_th * stat + b_th;
+            }
+            const float x = row[c];
+            float m;
+            if (diff) {
+                m = 0.5f * tanhf(steep * (x - th) + 2.5f) + 0.5f;
+                m = (fabsf(m) > 0.99f) ? m : 0.0f;
+            } else {
+                m = (x > th) ? 1.0f : 0.0f;
+            }
+            out[c] = m;
+        }
+        if (rn >= rows) break;
+        __syncthreads();                                            // everyone is done with this row's LDS image
+        stage();
+        __syncthreads();
+        r = rn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // R3 + R4: mean_peaks_parallel_fast (radar_utils.py:167-185) + extract_pc (:71-106).
 __device__ __forceinline__ float peak_value(const float *__restrict__ mrow, int j, int R, float res, int diff,
@@ -635,8 +711,21 @@ extern "C" int mmk_cfar_mask(const float *raw, int32_t B, int32_t A, int32_t R, 
     MMK_REQUIRE(smem <= 160 * 1024 - 64, "mmk_cfar_mask: R=%d does not fit the 160 KB LDS row buffer", R);
     if (smem > 64 * 1024)
         MMK_CHECK_HIP(hipFuncSetAttribute((const void *)cfar_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(cfar_mask_kernel, dim3(A, B), dim3(CFAR_T), smem, (hipStream_t)stream, raw, R, w2, guard, mincol,
-                       maxcol, a_thresh, b_thresh, diff, steep_fact, mask);
+    const int rows = A * B;
+    if (R <= 8 * CFAR_T && smem <= 40 * 1024) {
+        // persistent form: four blocks per CU (40 KB of LDS each), each with its next row in registers
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const int grid = std::min(rows, 4 * cus);
+        hipLaunchKernelGGL(cfar_mask_rows_kernel<8>, dim3(grid), dim3(CFAR_T), smem, (hipStream_t)stream, raw, rows, R, w2, guard, mincol,
+                           maxcol, a_thresh, b_thresh, diff, steep_fact, mask);
+    } else {
+        hipLaunchKernelGGL(cfar_mask_kernel, dim3(A, B), dim3(CFAR_T), smem, (hipStream_t)stream, raw, R, w2, guard, mincol,
+                           maxcol, a_thresh, b_thresh, diff, steep_fact, mask);
+    }
     MMK_LAUNCH_CHECK();
     return MMK_OK;
 }

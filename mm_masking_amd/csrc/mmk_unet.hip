@@ -2341,12 +2341,17 @@ struct UnpackBatch {
     int cout[PACK_BATCH_MAX], cin[PACK_BATCH_MAX], slices[PACK_BATCH_MAX];
 };
 
-// One block = 256 consecutive elements of a slice (64 lanes x float4: 1 KB contiguous per wave and
-// slice) x 4 groups of slices, LDS sum over the groups; weight sums go transposed to [co][ci][tap], bias
-// sums to db.  (Slice strides are multiples of 4 floats only when cout is: the tail is read scalar.)
+// A block's 256 threads are G groups of 256 / G lanes (G = 1, 4 or 16, picked per layer by its size: unpack_groups); a block
+// covers 4 * 256 / G consecutive elements of a slice, group g sums slices g, g + G, ... (sixteen float4 loads in flight per lane),
+// the groups' sums are added in group order through LDS.  Round 5: large layers read whole 4 KB runs of one slice per block
+// (G = 1: longer DRAM bursts, no LDS), small ones spread their many slices over 16 groups (the 8- and 16-channel layers have
+// ~2 000 slices of 0.6-2.3 K elements: at four groups a launch was bound by the serial chain over their slices) -- a fixed
+// association per element either way: deterministic.  Weight sums go transposed to [co][ci][tap], bias sums to db.
+__host__ __device__ inline int unpack_groups(int total) { return total < 8192 ? 16 : (total < 65536 ? 4 : 1); }
+
 __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch ub)
 {
-    __shared__ float red[4][256 + 4];
+    __shared__ float red[16][64 * 4 + 4];             // [group][element of the block] for G = 16 (64 elements) and G = 4 (256)
     const int l = blockIdx.y;
     const int COUT = ub.cout[l], CIN = ub.cin[l];
     const int nw = COUT * CIN * 9;
@@ -2356,49 +2361,58 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
     const float *__restrict__ src = ub.src[l];
     float *__restrict__ dst = ub.dW[l];
     float *__restrict__ dbo = ub.db[l];
-    const int ln = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const bool vec = (total & 3) == 0;                // float4 path: slices stay 16-byte aligned
-    for (int e0 = blockIdx.x * 256; e0 < total; e0 += gridDim.x * 256) {
-        const int e = e0 + 4 * ln;
+    const int G = unpack_groups(total), tpg = 256 / G, epb = 4 * tpg;
+    const int sg = threadIdx.x / tpg, tl = threadIdx.x % tpg;
+    auto put = [&](int ee, float t) {
+        if (ee < nw) {
+            const int ci = ee % CIN, co = (ee / CIN) % COUT, tap = ee / (CIN * COUT);
+            dst[((size_t)co * CIN + ci) * 9 + tap] = t;
+        } else if (ee < total && dbo) {
+            dbo[ee - nw] = t;
+        }
+    };
+    for (int e0 = blockIdx.x * epb; e0 < total; e0 += gridDim.x * epb) {      // (block-uniform trip count: the barriers are safe)
+        const int e = e0 + 4 * tl;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (vec && e + 3 < total) {
+            const float *p = src + e;
             int sl = sg;
-            // eight slices in flight per lane (the sums stay in slice order)
-            for (; sl + 28 < S; sl += 32) {
-                float4 t[8];
+            for (; sl + 15 * G < S; sl += 16 * G) {
+                float4 t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4 *>(src + (size_t)(sl + 4 * u) * total + e);
+                for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float4 *>(p + (size_t)(sl + u * G) * total);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w;
                 }
             }
-            for (; sl < S; sl += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)sl * total + e);
+            for (; sl < S; sl += G) {
+                const float4 t = *reinterpret_cast<const float4 *>(p + (size_t)sl * total);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
         } else {
-            for (int sl = sg; sl < S; sl += 4)
+            for (int sl = sg; sl < S; sl += G)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (e + j < total) v[j] += src[(size_t)sl * total + e + j];
         }
+        if (G == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[sg][4 * ln + j] = v[j];
-        __syncthreads();
-        {
-            const int ee = e0 + threadIdx.x;
-            if (ee < total) {
-                const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-                if (ee < nw) {
-                    const int ci = ee % CIN, co = (ee / CIN) % COUT, tap = ee / (CIN * COUT);
-                    dst[((size_t)co * CIN + ci) * 9 + tap] = t;
-                } else if (dbo) {
-                    dbo[ee - nw] = t;
-                }
+            for (int j = 0; j < 4; ++j) put(e + j, v[j]);
+        } else {
+            // (G = 4: 256 elements per block, stored as four 64-element rows per group)
+            float *row = &red[0][0] + (size_t)sg * (epb + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row[4 * tl + j] = v[j];
+            __syncthreads();
+            for (int k = threadIdx.x; k < epb; k += 256) {
+                float t = 0.f;
+                for (int g = 0; g < G; ++g) t += (&red[0][0])[(size_t)g * (epb + 4) + k];
+                put(e0 + k, t);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -3658,16 +3672,18 @@ extern "C" int mmk_conv3x3_wgrad_unpack_batch(int32_t n, const float *const *src
     for (int base = 0; base < n; base += PACK_BATCH_MAX) {
         UnpackBatch ub;
         const int m = std::min(PACK_BATCH_MAX, n - base);
-        int most = 0;
+        int most = 0;       // blocks the layer with the most of them needs
         for (int i = 0; i < PACK_BATCH_MAX; ++i) {
             const int k = base + (i < m ? i : 0);
             MMK_REQUIRE(src[k] && dW[k] && cout[k] >= 1 && cin[k] >= 1, "mmk_conv3x3_wgrad_unpack_batch: bad layer %d", k);
             ub.src[i] = src[k]; ub.dW[i] = dW[k]; ub.cout[i] = cout[k]; ub.cin[i] = cin[k];
             ub.slices[i] = slices ? slices[k] : 0;
             ub.db[i] = (db && ub.slices[i] > 0) ? db[k] : nullptr;
-            most = std::max(most, cout[k] * cin[k] * 9 + cout[k]);
+            const int total = cout[k] * cin[k] * 9 + (ub.slices[i] > 0 ? cout[k] : 0);
+            const int epb = 4 * (256 / unpack_groups(total));
+            most = std::max(most, (total + epb - 1) / epb);
         }
-        const unsigned bx = (unsigned)std::min((most + 255) / 256, 1024);
+        const unsigned bx = (unsigned)std::min(most, 2048);
         hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, ub);
         MMK_LAUNCH_CHECK();
     }
