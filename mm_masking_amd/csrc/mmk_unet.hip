@@ -433,7 +433,14 @@ int launch_conv(const ConvArgs &a, hipStream_t st)
 __device__ u32x4 g_zero16;   // zero-initialised, never written
 __device__ u32x4 g_zero32[2];   // (32 bytes of them)
 __device__ u32x4 g_sink32[2];   // where the unconditional stores of lanes without an output go
-__device__ u32x4 g_sink16[8]; // write-only: where lanes without an output element store
+}  // namespace
+// write-only: where lanes without an output element store.  External linkage on purpose: stores to an INTERNAL variable that
+// nothing reads are deleted by the compiler, and the ring kernel's prologue issues stores to it only to give the first round
+// the load / store queue of every later one (round 5: they had been deleted, and hipcc's merged loop-head state then made every
+// stage wait for all but the last one or two of the loads in flight -- the ring was one tile deep instead of RD)
+__device__ mmku::u32x4 mmk_sink16[8];
+namespace {
+#define g_sink16 mmk_sink16
 
 __device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8])
 {
@@ -457,6 +464,9 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef MMK_RING_DIAG
+#define MMK_RING_DIAG 0      // diagnostic builds (scripts/build_variant.sh): 1 = no output stores, 2 = no input loads
+#endif
 // POOL: 0 = no pooling; 1 = the output and its 2x2 max-pool (pool_y); 2 = the max-pool and its arg-max codes (pool_y, pool_arg)
 // only: the full-resolution output is not written at all (the backward pass routes the pooled gradient by the codes,
 // maxpool2_bwd_arg_kernel, and nothing else reads the block's pre-pool output)
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
         _Pragma("unroll") for (int i = 0; i < RIN; ++i) {                                                    \
             const bool ok = (unsigned)(ty0_ + g_dy[i]) < (unsigned)a.H && (unsigned)(tx0_ + g_dx[i]) < (unsigned)a.W; \
             const bf16 *src = (in_x2[i] ? base2_ : base1_) + in_off[i];                                      \
-            const u32x4 *sp = ok ? reinterpret_cast<const u32x4 *>(src) : &g_zero16;                         \
+            const u32x4 *sp = (ok && MMK_RING_DIAG != 2) ? reinterpret_cast<const u32x4 *>(src) : &g_zero16; \
             rin[SLOT][i] = *sp;                                                                              \
         }                                                                                                    \
         /* next tile of the walk (parks on the block's last tile: the ring keeps re-loading it) */           \
@@ -683,8 +693,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     // The first round is peeled off the loop: hipcc merges the load/store queue state of every edge
     // into the loop header by its minimum, and the prologue's short queue would otherwise turn the
     // header's wait for tile k+1 into a drain of the whole ring on every round.
+    // Round 5: and the loop itself runs WHOLE rounds only (no exit test between its stages), the last < RD tiles are a tail
+    // behind it.  With `if (k >= nt_blk) goto ring_done` in front of every stage of the loop the compiler's single-exit form
+    // of the loop was "skip this stage's body, raise a flag, go on to the latch": control-flow paths on which a stage's loads
+    // and stores were not issued reach the loop header, the merged queue state there guaranteed only the last one or two
+    // entries, and every stage waited with vmcnt(2) / (1) / (0) where (3 RD - 1) was meant -- the ring was one tile deep
+    // (and the third stage also waited for the previous stage's store to complete).
     int k0 = 0;
     {
+#define STAGE_CHECKED 1
 #define STAGE_SLOT 0
 #include "mmk_conv_ring_stage.inc"
 #undef STAGE_SLOT
@@ -696,8 +713,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
 #include "mmk_conv_ring_stage.inc"
 #undef STAGE_SLOT
         }
+#undef STAGE_CHECKED
     }
-    for (k0 = RD;; k0 += RD) {
+    for (k0 = RD; k0 + RD <= nt_blk; k0 += RD) {
+#define STAGE_CHECKED 0
 #define STAGE_SLOT 0
 #include "mmk_conv_ring_stage.inc"
 #undef STAGE_SLOT
@@ -709,6 +728,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
 #include "mmk_conv_ring_stage.inc"
 #undef STAGE_SLOT
         }
+#undef STAGE_CHECKED
+    }
+    {   // tail: the last nt_blk % RD tiles
+#define STAGE_CHECKED 1
+#define STAGE_SLOT 0
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        if constexpr (RD > 2) {
+#define STAGE_SLOT 1
+#include "mmk_conv_ring_stage.inc"
+#undef STAGE_SLOT
+        }
+#undef STAGE_CHECKED
     }
 ring_done:;
 #undef MMK_RING_LOAD

@@ -24,3 +24,12 @@ for H, cin, co in [(640, 8, 8), (640, 8, 16), (640, 16, 16), (640, 16, 8), (320,
     t = timeit(lambda: uh.conv3x3(x, wp, co, bias=bias, relu=True, drop_p=drop, seed=3, out=y))
     res.append("%d:%d>%d %.1f us %.2f TB/s" % (H, cin, co, t, B * H * H * (cin + co) * 2 / t * 1e-6))
 print("drop %.2f |" % drop, " | ".join(res))
+if os.environ.get("COPY_REF"):
+    # what a plain device copy of the same tensors reaches (read N bytes + write N bytes)
+    out = []
+    for H, c in [(640, 8), (640, 16), (320, 32)]:
+        x = torch.randn(B, H, H, c, device=DEV).to(torch.bfloat16)
+        y = torch.empty_like(x)
+        t = timeit(lambda: y.copy_(x))
+        out.append("%d:%d %.1f us %.2f TB/s" % (H, c, t, 2 * x.numel() * 2 / t * 1e-6))
+    print("torch copy |", " | ".join(out))
