@@ -464,6 +464,24 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Diagnostic build only (-DMMK_DEEP_STAMPS; scripts/deep_stamps.py): the first 64 blocks record s_memtime at eight points of each
+// of their first MMK_STAMP_STAGES stages, per wave, in LDS, and copy them to a caller's buffer when they exit (conv3x3_ring_kernel:
+// the same per tile, plus every block's start and end on the 100 MHz clock: scripts/ring_stamps.py).  The shipped library
+// contains none of this.
+#ifdef MMK_DEEP_STAMPS
+constexpr int MMK_STAMP_STAGES = 24;
+__device__ unsigned long long *g_deep_stamp_buf = nullptr;
+#define MMK_STAMP(K)                                                                                          \
+    do {                                                                                                      \
+        if (stamp_stage < MMK_STAMP_STAGES) {                                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
+            if (lane == 0) stamp_lds[(wv * MMK_STAMP_STAGES + stamp_stage) * 8 + (K)] = t_;                    \
+        }                                                                                                     \
+    } while (0)
+#else
+#define MMK_STAMP(K) do { } while (0)
+#endif
+
 #ifndef MMK_RING_DIAG
 #define MMK_RING_DIAG 0      // diagnostic builds (scripts/build_variant.sh): 1 = no output stores, 2 = no input loads
 #endif
@@ -500,7 +518,22 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
     const int first = t_begin + (blockIdx.x >> 3);
     if (first >= t_end) return;
     const int nt_blk = (t_end - first + nb - 1) / nb;         // tiles of this block: first + k * nb
+#ifdef MMK_DEEP_STAMPS
+    unsigned long long *stamp_lds = reinterpret_cast<unsigned long long *>(smem + ((size_t)(2 * HT * WT * PK + NS * MT * 512) * sizeof(bf16) + 15) / 16 * 16);
+    int stamp_stage = 0;
+    for (int i = tid; i < 4 * MMK_STAMP_STAGES * 8; i += CONV_THREADS) stamp_lds[i] = 0ull;
+    __syncthreads();
+    if (tid == 0) {     // (slots 6, 7 of a stage are free)
+        stamp_lds[6] = gridDim.x; stamp_lds[7] = (unsigned long long)nt_blk;
+        stamp_lds[8 + 6] = __builtin_amdgcn_s_memtime(); stamp_lds[8 + 7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
+    // (Tried, round 5, no gain: a rotating raised wave priority.  The CU's issue arbiter prefers the OLDEST wave, so of the blocks
+    // that share a CU the first one dispatched finishes its tiles in 52 us and the last in 96 us of a 99 us launch
+    // (scripts/ring_stamps.py).  Handing s_setprio 2 to another wave slot every 4 096 cycles narrows that to 59 .. 97 us and moves
+    // the launch by nothing, and so does giving blocks 4-24 consecutive tiles each and leaving the balance to the hardware
+    // dispatcher (slower): two or more resident blocks already keep the CU as busy as five do, profiles/r05_ring_stamps.txt.)
     u32x4 rin[RD][RIN];
     // Everything per-lane that does not depend on the tile is worked out once: addresses inside the
     // loop are then "uniform tile origin (scalar unit) + 32-bit lane offset", a handful of VALU
@@ -743,6 +776,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_ring_kernel(const ConvAr
 #undef STAGE_CHECKED
     }
 ring_done:;
+#ifdef MMK_DEEP_STAMPS
+    if (tid == 0) { stamp_lds[16 + 6] = __builtin_amdgcn_s_memtime(); stamp_lds[16 + 7] = __builtin_amdgcn_s_memrealtime(); }
+    __syncthreads();
+    // every block of the first 4 096: when it started and ended (100 MHz clock), behind the first 64 blocks' stamps
+    if (g_deep_stamp_buf != nullptr && blockIdx.y == 0 && blockIdx.x < 4096 && tid == 0) {
+        unsigned long long *life = g_deep_stamp_buf + (size_t)64 * (4 * MMK_STAMP_STAGES * 8) + (size_t)blockIdx.x * 2;
+        life[0] = stamp_lds[8 + 7];
+        life[1] = stamp_lds[16 + 7];
+    }
+    if (g_deep_stamp_buf != nullptr && blockIdx.y == 0 && blockIdx.x < 64)
+        for (int i = tid; i < 4 * MMK_STAMP_STAGES * 8; i += CONV_THREADS)
+            g_deep_stamp_buf[(size_t)blockIdx.x * (4 * MMK_STAMP_STAGES * 8) + i] = stamp_lds[i];
+#endif
 #undef MMK_RING_LOAD
 #undef MMK_RING_STORE
 }
@@ -750,7 +796,12 @@ ring_done:;
 template <int CK, int CM, int RD, bool EPI, int POOL = 0, bool C8 = false>
 int launch_conv_ring(const ConvArgs &a, hipStream_t st)
 {
+#ifdef MMK_DEEP_STAMPS
+    const size_t smem = (((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16) + 15) / 16 * 16 +
+                        (size_t)4 * MMK_STAMP_STAGES * 8 * sizeof(unsigned long long);
+#else
     const size_t smem = ((size_t)2 * HT * WT * lds_pitch(CK) + (size_t)ksteps(CK) * (CM / 16) * 512) * sizeof(bf16);
+#endif
     static int per_cu[64] = {};     // resident blocks per CU (registers / LDS), per device
     int dev = 0;
     MMK_CHECK_HIP(hipGetDevice(&dev));
@@ -816,23 +867,6 @@ int launch_conv_ring_epi(const ConvArgs &a, hipStream_t st)
 // picked per layer (NT = 3 for 40-pixel rows, 5 for 80 / 160) so that no MFMA column is wasted
 // on padding.  Wave (wm, wn) owns output channels [wm*MT*16, +MT*16) of tile row wn.
 constexpr int DEEP_THREADS = 512;
-
-// Diagnostic build only (-DMMK_DEEP_STAMPS; scripts/deep_stamps.py): the first 64 blocks record s_memtime at eight points of each
-// of their first MMK_STAMP_STAGES stages, per wave, in LDS, and copy them to a caller's buffer when they exit.  The shipped
-// library contains none of this.
-#ifdef MMK_DEEP_STAMPS
-constexpr int MMK_STAMP_STAGES = 24;
-__device__ unsigned long long *g_deep_stamp_buf = nullptr;
-#define MMK_STAMP(K)                                                                                          \
-    do {                                                                                                      \
-        if (stamp_stage < MMK_STAMP_STAGES) {                                                                 \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
-            if (lane == 0) stamp_lds[(wv * MMK_STAMP_STAGES + stamp_stage) * 8 + (K)] = t_;                    \
-        }                                                                                                     \
-    } while (0)
-#else
-#define MMK_STAMP(K) do { } while (0)
-#endif
 
 template <int BM, int NT>
 struct DeepCfg {
