@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+# before anything initialises HIP (mm_masking_amd/__init__.py says why; the rank processes inherit it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def usable_cores():
     """Host cores this process may actually use: affinity mask, capped by the cgroup
@@ -373,6 +376,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="ONE gradient all-reduce between backward and step instead of the three bucket all-reduces that overlap "
                          "the backward pass (mm_masking_amd/ddp.py)")
+    ap.add_argument("--local-minmax", action="store_true",
+                    help="(diagnostic) keep the min-max normalisation per rank in a --force-dist / N-rank run: no collective in the forward pass")
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
@@ -418,7 +423,10 @@ def main():
     model = LearnICPWeightPolicy(params).to(device)
     model.train()
     opt = trn.make_optimizer(model, params)
-    if args.force_dist:
+    if args.local_minmax:
+        params["global_minmax"] = False
+        model.global_minmax = False
+    elif args.force_dist:
         params["global_minmax"] = True          # the 2C-float MAX all-reduce in front of the first layer, as in an N-rank job
         model.global_minmax = True
         from mm_masking_amd import unet_hip
@@ -566,11 +574,11 @@ def main():
             scanned = float((N_PAD - 512 * skipped.sum(dim=1)).float().mean().item())
         evals = active_pairs * scanned * M_PAD       # distance evaluations per launch
         # HBM bytes per launch from the PMC counters: NOT measured in this run -- read from a committed file that a separate
-        # rocprofv3 --pmc pass over the dICP alone wrote (scripts/pmc_nn.sh -> profiles/r04_nn_traffic.json, FETCH_SIZE and
+        # rocprofv3 --pmc pass over the dICP alone wrote (scripts/pmc_nn.sh -> profiles/r05_nn_traffic.json, FETCH_SIZE and
         # WRITE_SIZE in passes of their own, FETCH_SIZE doubled per the gfx950 correction); null when no such file exists.
         # `traffic_source` says so in the line itself.
         traffic, traffic_source = None, None
-        for name in ("r04_nn_traffic.json", "r03_nn_traffic.json", "r02_nn_traffic.json"):
+        for name in ("r05_nn_traffic.json", "r04_nn_traffic.json", "r03_nn_traffic.json", "r02_nn_traffic.json"):
             tr_file = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tr_file) and model.ICP_alg.nn_search == "brute":
                 tj = json.load(open(tr_file))
@@ -593,7 +601,7 @@ def main():
                    "frac": evals / nn_avg_s / peak_pairs,
                    "equivalent_dense_bf16_tflops": evals / nn_avg_s * 32 / 1e12,
                    "note": "16 k-slots (2 x 16 flop) per pair: exact three-way bf16 splits of -2p, t and |t|^2, fp32 accumulation; "
-                           "1.1 vector instructions per 64 pairs beside the MFMAs (profiles/r04_nn_pmc_counters.json; the fp32 VALU "
+                           "1.1 vector instructions per 64 pairs beside the MFMAs (profiles/r05_nn_pmc_counters.json; the fp32 VALU "
                            "kernel of rounds 1-2, removed in round 5, issued 3.3)"}
         result = {
             "metric": "scan-pairs/s (mask-CNN + 10-iter dICP fwd+bwd)", "value": B * world * args.steps / dt,

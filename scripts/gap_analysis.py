@@ -14,7 +14,16 @@ st = [t for t in tabs if t.startswith("rocpd_string")][0]
 cols = [r[1] for r in db.execute("pragma table_info(%s)" % kt).fetchall()]
 sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = db.execute("select s.kernel_name, k.start, k.end from %s k join %s s on k.kernel_id = s.id order by k.start" % (kt, sym)).fetchall()
-marks = [i for i, r in enumerate(rows) if "cfar_mask_kernel" in r[0]]
+# memory copies / fills done by the copy engines or blit paths are no kernels: with --memory-copy-trace they are in a table of their own
+for t in [t for t in tabs if t.startswith("rocpd_memory_copy")]:
+    try:
+        mc = db.execute("select start, end, size from %s" % t).fetchall()
+        rows += [("memcpy %d B" % (sz or 0), s_, e_) for s_, e_, sz in mc]
+        print("memory copies in the trace:", len(mc))
+    except Exception as ex:      # (schema differs between versions: report and go on with kernels only)
+        print("memory-copy table %s not read: %s" % (t, ex))
+rows.sort(key=lambda r: r[1])
+marks = [i for i, r in enumerate(rows) if "cfar_mask" in r[0]]
 print("kernels", len(rows), "steps seen", len(marks))
 segs = [(a, b) for a, b in zip(marks[:-1], marks[1:]) if rows[b][1] - rows[a][1] < 15e6]      # (steps of the timed region: < 15 ms)
 for a, b in segs[-3:]:
@@ -40,3 +49,9 @@ for a, b in segs[-3:]:
     print("   gap histogram (us: count):", dict(sorted(hist.items())))
     for g, s, e, name in gaps[:14]:
         print("   gap %.1f us: %s" % (g / 1e3, name[:140]))
+    # the launches around the two largest gaps, with start / duration relative to the step's first kernel (us)
+    for g, s, e, name in gaps[:2]:
+        idx = [i for i, r in enumerate(seg) if r[1] == e][0]
+        print("   around the %.1f us gap:" % (g / 1e3))
+        for name2, s2, e2 in seg[max(0, idx - 8):idx + 4]:
+            print("      %9.1f  +%7.1f us  %s" % ((s2 - t0) / 1e3, (e2 - s2) / 1e3, short(name2)))

@@ -86,7 +86,7 @@ def test_device_loader_equals_default_items(golden_dir, tmp_path, mode):
 
 def test_loader_throughput_against_step_rate(tmp_path):
     """Full-size export (400 x 3371 Navtech PNG rows, 5 120-row scan clouds, 20 480-row maps): what the loader delivers per
-    second next to what the training step consumes at B = 32.  The numbers go to gpurun_out/r04_loader.json; the assertion is
+    second next to what the training step consumes at B = 32.  The numbers go to gpurun_out/r05_loader.json; the assertion is
     that a step fed by the loader (staging overlapped on the side stream) trains on the loader's batches and that the
     loader's rate is reported -- whether it keeps up depends on the host (it is memcpy-bound: ~3.3 MB per item)."""
     import export_util
@@ -165,7 +165,7 @@ def test_loader_throughput_against_step_rate(tmp_path):
     assert torch.isfinite(loss)
     try:
         os.makedirs(OUT, exist_ok=True)
-        json.dump(res, open(os.path.join(OUT, "r04_loader.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(OUT, "r05_loader.json"), "w"), indent=1)
     except OSError:
         pass
     print(res)
