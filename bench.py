@@ -120,6 +120,11 @@ def launch_ranks(argv, n, runner=None):
     if line is None:
         sys.stderr.write("[bench] the ranks exited cleanly but rank 0 printed no result line\n")
         return 3
+    # whatever else the ranks wrote to stdout (RCCL's NCCL_DEBUG=INFO lines, for one) goes to this process's stderr: stdout stays
+    # the one result line
+    for other in (proc.stdout or "").splitlines():
+        if other.strip() and other.strip() != line.strip():
+            sys.stderr.write("[rank stdout] " + other + "\n")
     print(line)
     sys.stdout.flush()
     return 0

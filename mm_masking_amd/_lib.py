@@ -91,7 +91,7 @@ def build(verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
     # mmk_unet.hip: MFMA results in VGPRs instead of AGPRs.  The thin-layer kernels are bound by vector-instruction issue and the
     # compiler's default parks their accumulators in AGPRs, which vector instructions cannot read: every output value then costs
-    # a v_accvgpr_read (4 184 of them in the file, 96 with the option; same arithmetic, same or better occupancy)
+    # a v_accvgpr_read (4 184 of them in the file, 96 with the option; same arithmetic, same or better occupancy; HISTORY.md 10.17)
     per_file = {"mmk_unet.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     jobs, objs = [], []
     for src in srcs:

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NN_THREADS, DIM == 2 ? 4 : 3) void nn_mfma_kernel(
         // read as `half ? p[2 + q] : p[q]` they became a 48-byte scratch-memory array read back at a run-time offset; with that
         // build 16-lane groups of a wave now and then worked on wrong coordinates (correspondences that changed from run to
         // run; a NaN coordinate finds nothing, so keys that nobody armed).  The round trip is sound in isolation
-        // (scripts/ubench/scratch_roundtrip.hip) and so is the code object; what failed in the full
+        // (scripts/ubench/scratch_roundtrip.hip) and so is the code object (HISTORY.md section 10); what failed in the full
         // process is not established.  The library uses no scratch memory anywhere:
         // tests/test_code_objects.py::test_no_kernel_uses_scratch_memory.
         float px[NNM_GROUPS], py[NNM_GROUPS], pz[NNM_GROUPS], c2[NNM_GROUPS], brun[NNM_GROUPS], thr[NNM_GROUPS], dseed[NNM_GROUPS];

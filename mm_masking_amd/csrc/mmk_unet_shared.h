@@ -46,7 +46,7 @@ struct ConvArgs {
 // 16-bit draws compared against thr = round(p * 65536).  Round 4: the draws come from a hash built on FULL-RATE 24-bit
 // multiplies (v_mad_u32_u24 / v_mul_u32_u24).  The avalanche hash of rounds 1-3 used 32-bit multiplies, which are quarter
 // rate on the VALU: three of them per four values were half of the forward epilogues of the issue-bound kernels (switching
-// dropout off moved the thin 640 x 640 forward launches by 13-30 us each).  Nothing downstream depends on
+// dropout off moved the thin 640 x 640 forward launches by 13-30 us each, HISTORY.md 9.10).  Nothing downstream depends on
 // WHICH elements are dropped -- the backward kernels read the mask back from the stored activation -- only on the rate and
 // on independence (scripts/dropout_hash_check.py; the chain itself: below).
 struct DropoutParams {

@@ -1,4 +1,4 @@
-// EXPERIMENT, NOT PART OF THE BUILD (round 4).  Kept as the record of the LDS-DMA rebuild of conv3x3_deep_kernel; DESIGN.md section 10
+// EXPERIMENT, NOT PART OF THE BUILD (round 4).  Kept as the record of the LDS-DMA rebuild of conv3x3_deep_kernel; HISTORY.md section 10
 // has the measurements: bit-identical to the deep kernel at p = 0, within -10 % ... +9 % of its time (it wins at 160 x 160 forward only),
 // because what bounds these launches is not the staging path.  To build it again: add it to _lib.SOURCES, declare
 // conv_dx_dispatch() / dropout_draws4_fast() (= dropout_draws4) in mmk_unet_shared.h and call it from dispatch_conv_deep().

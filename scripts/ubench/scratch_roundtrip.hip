@@ -1,5 +1,5 @@
 // Does a small per-lane scratch array survive a store -> (work) -> load-at-run-time-offset round trip in a persistent kernel?
-// Mimics what the first cut of nn_mfma_kernel did with its point coordinates: per unit, 8 floats per lane are
+// Mimics what the first cut of nn_mfma_kernel did with its point coordinates (HISTORY.md 9.1): per unit, 8 floats per lane are
 // written through a pointer (so that they live in scratch), a few thousand cycles of LDS + MFMA work follow, then 4 of them are
 // read back at an offset that depends on the lane's half.  Counts read-backs that differ from the value the lane computed.
 //   hipcc --offload-arch=gfx950 -O3 -o scratch_roundtrip scratch_roundtrip.hip && ./scratch_roundtrip
