@@ -61,6 +61,22 @@ def test_cfar_full_size_vs_oracle():
     assert 500 < want[0].sum() < 40000
 
 
+def test_cfar_long_rows_take_the_one_row_per_block_kernel():
+    """Rows whose prefix sums do not fit 40 KB of LDS (more than 3 412 range bins) run on cfar_mask_kernel, one row per block,
+    instead of the persistent cfar_mask_rows_kernel: same masks as the oracle there too, and as the persistent kernel's on
+    the columns both see."""
+    rng = np.random.default_rng(11)
+    raw = rng.random((2, 5, 4000), dtype=np.float32) * 0.2
+    raw[:, :, 700:3900:97] += 0.6
+    got = ru.cfar_mask(_g(raw), 0.0596, diff=False).cpu().numpy()
+    want = R.cfar_mask(raw, 0.0596, diff=False)
+    _mask_close(raw, got, want, R.cfar_threshold(raw, 0.0596))
+    assert 20 < want.sum() < 5000
+    soft = ru.cfar_mask(_g(raw), 0.0596, diff=True).cpu().numpy()
+    d = np.abs(soft - R.cfar_mask(raw, 0.0596, diff=True))
+    assert (d > 0.5).mean() < 1e-3 and d[d <= 0.5].max() < 2e-5
+
+
 def test_extract_pc_golden(golden_dir):
     g = _load(golden_dir, "radar_peaks.npz")
     mask = g["mask"].astype(np.float32)
