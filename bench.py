@@ -21,8 +21,12 @@ import os
 import sys
 import time
 
-# before anything initialises HIP (mm_masking_amd/__init__.py says why; the rank processes inherit it)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A rank of an RCCL job (one process per GPU): eight hardware queues instead of ROCm's four, so that the step's streams -- the
+# caller's, the weight-gradient side stream, the gradient all-reduce's communication stream, RCCL's own -- do not share queues
+# (0.2 ms per step in the one-rank rehearsal).  Before anything initialises HIP; an explicit setting
+# wins; not for gloo rehearsals, where several ranks share one GPU and more queues per process means slower time-slicing.
+if "WORLD_SIZE" in os.environ and os.environ.get("MMK_BENCH_BACKEND", "nccl") == "nccl":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def usable_cores():

@@ -222,8 +222,17 @@ int side_stream(SideStream **out)
     MMK_CHECK_HIP(hipGetDevice(&dev));
     SideStream &s = pool[dev & 15];
     if (s.st == nullptr || s.dev != dev) {
-        // (a highest-priority stream changes nothing: round 5, gpurun_out/r05_call8.txt)
-        MMK_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        // Highest priority -- not for the priority's sake (it changes nothing in a process with few streams) but because ROCm maps
+        // the streams of a priority class onto that class's own hardware queues: once a process group exists (RCCL's streams, the
+        // communication stream of ddp.FlatGradSync) a default-priority side stream created after them lands on the SAME hardware
+        // queue as the caller's stream (4 queues per process by default, handed out in creation order), its launches serialise
+        // behind the data-gradient chain and the backward pass loses the whole overlap: 4.7 -> 5.2 ms at B = 32
+        // (bench.py --gpus 1 --force-dist, profiles/r05_hw_queues_ab.txt).
+        {
+            int lo = 0, hi = 0;
+            MMK_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MMK_CHECK_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
+        }
         MMK_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         MMK_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         s.dev = dev;

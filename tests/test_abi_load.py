@@ -81,19 +81,3 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "from oracle" not in txt and "import oracle" not in txt, f
 
-
-def test_import_sets_hardware_queue_default_without_overriding():
-    """mm_masking_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 (the weight-gradient side stream must not share a hardware queue
-    with the caller's stream once RCCL's streams exist); an explicit setting wins."""
-    import subprocess
-    import sys
-    code = "import os; import mm_masking_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    assert out.stdout.strip().splitlines()[-1] == "8"
-    env["GPU_MAX_HW_QUEUES"] = "4"
-    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    assert out.stdout.strip().splitlines()[-1] == "4"
